@@ -1,0 +1,241 @@
+/*
+ * sbtv.h — C-ABI of libsbtv.so: the MI355X (gfx950) implementation of the
+ * FFT-convolution + TV-proximal inner loop of SALSA / FISTA / SAPG(MYULA).
+ *
+ * The reference (charles-kmc/Semi-blind-image-deblurring-problems-with-TV) is
+ * pure MATLAB and has no FFI layer: its "operator API" is function handles
+ * and name/value option lists.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).  A host
+ * binds these with MATLAB loadlibrary/calllib (this header is plain C, no
+ * mex.h), a MEX gateway, or Python ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all image buffers are IEEE double, column-major (MATLAB layout):
+ *     element (i,j) of image b lives at  buf[b*M*N + j*M + i],  M rows, N cols.
+ *   - M and N must be powers of two, 16 <= M, N <= 4096 for every entry point
+ *     that applies the blur operator (hand-written radix-2^k FFT).  The TV
+ *     entry points (prox, TVnorm) accept any M >= 2, N >= 2.
+ *   - `flags & SBTV_DEVICE_PTRS`: image buffers are device pointers on the
+ *     context's GPU (no PCIe copies; asynchronous on the context stream).
+ *     Otherwise they are host pointers and the call copies in/out and returns
+ *     after the results are on the host.  Small option/result arrays
+ *     (scalars per image, traces) are ALWAYS host pointers.
+ *   - return value: 0 = ok; < 0 argument errors (mirror the reference's
+ *     error() sites); > 0 HIP runtime errors.  sbtv_last_error() gives text.
+ *     Nothing throws across the boundary.
+ *   - one context = one GPU = one host thread at a time.
+ */
+#ifndef SBTV_H
+#define SBTV_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBTV_VERSION 100
+
+/* flags */
+#define SBTV_HOST_PTRS   0
+#define SBTV_DEVICE_PTRS 1
+
+/* status codes */
+#define SBTV_OK                   0
+#define SBTV_ERR_BADARG          -1   /* generic bad argument                                  */
+#define SBTV_ERR_SIZE            -2   /* unsupported image size (non power of two for the FFT) */
+#define SBTV_ERR_MAXITER         -3   /* chambolle: 'maxiter' missing  (chambolle_prox_TV_stop.m:95,131, quirk Q1) */
+#define SBTV_ERR_DUALVARS        -4   /* 'Wrong size of the dual variables' (chambolle_prox_TV_stop.m:103)          */
+#define SBTV_ERR_MODE            -5   /* 'The value of parameter mode must be 1 or 2' (A_wrapper.m:15)              */
+#define SBTV_ERR_STOPCRITERION   -6   /* 'Unknown stopping criterion' (SALSA_v2.m:246; my_fista.m:45)               */
+#define SBTV_ERR_INIT            -7   /* "Unknown 'Initialization' option" (SALSA_v2.m:382)                          */
+#define SBTV_ERR_MISSING_AT      -8   /* 'The function handle for transpose of A is missing' (SALSA_v2.m:262)        */
+#define SBTV_ERR_MISSING_LS      -9   /* '(A^T A + mu I)^(-1) must be specified' (SALSA_v2.m:296)                    */
+#define SBTV_ERR_PSF            -10   /* bad PSF size / mask does not fit (conv2c.m:15)                               */
+#define SBTV_ERR_NOMEM          -11
+#define SBTV_ERR_NODEVICE       -12   /* no usable GPU: the library has NO CPU fallback                               */
+
+typedef struct sbtv_ctx sbtv_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int         sbtv_version(void);
+/* Create a context on GPU `device`.  Fails with SBTV_ERR_NODEVICE when no
+ * gfx950-capable device is visible (there is deliberately no CPU path). */
+int         sbtv_ctx_create(int device, sbtv_ctx **out);
+int         sbtv_ctx_destroy(sbtv_ctx *ctx);
+const char *sbtv_last_error(const sbtv_ctx *ctx);   /* ctx may be NULL: global message */
+/* Use an externally owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
+int         sbtv_ctx_set_stream(sbtv_ctx *ctx, void *hip_stream);
+int         sbtv_ctx_sync(sbtv_ctx *ctx);
+/* Operator-call counters: the reference's global `calls` (SALSA/callcounter.m:8-15). */
+int         sbtv_callcounter_get(const sbtv_ctx *ctx, long long *calls);
+int         sbtv_callcounter_reset(sbtv_ctx *ctx);
+/* Timing of the most recent solver call, measured with HIP events on the
+ * context stream: [0] total ms of the iteration loop, [1] ms inside the
+ * Chambolle iteration kernels, [2] number of Chambolle iteration launches,
+ * [3] algorithmic bytes those launches moved (40 B/pixel/iteration). */
+int         sbtv_last_timing(const sbtv_ctx *ctx, double out[4]);
+
+/* raw device memory helpers so hosts without a GPU array type (MATLAB) can
+ * keep buffers resident between calls */
+int         sbtv_malloc(sbtv_ctx *ctx, size_t bytes, void **dptr);
+int         sbtv_free(sbtv_ctx *ctx, void *dptr);
+int         sbtv_memcpy_h2d(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes);
+int         sbtv_memcpy_d2h(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* ---- a-1: TV proximal operator ----------------------------------------
+ * Replaces  [f,px,py] = chambolle_prox_TV_stop(g,'lambda',L,'maxiter',K,
+ *                        'tol',t,'tau',T,'dualvars',[px py])
+ * (utils/chambolle_prox_TV_stop.m:1-166), batched over `batch` images.
+ *   lambda[batch]   regularisation weight per image
+ *   maxiter         REQUIRED, > 0 (quirk Q1) else SBTV_ERR_MAXITER
+ *   tol, tau        reference defaults 1e-3, 0.249 (:77-78)
+ *   warm_start      0: px=py=0 (:68-69); 1: px,py hold the dual variables on entry (:99-107)
+ *   px,py,f         M*N*batch each; px,py always written; f may be NULL
+ *   k_out[batch]    iterations actually run;  err_out[batch] last `err` (:128)
+ */
+int sbtv_chambolle_prox_TV_stop(sbtv_ctx *ctx, const double *g, int M, int N, int batch,
+                                const double *lambda, int maxiter, double tol, double tau,
+                                int warm_start, double *px, double *py, double *f,
+                                int *k_out, double *err_out, int flags);
+
+/* ---- a-2: periodic isotropic TV ----------------------------------------
+ * Replaces  TVnorm(x)  (utils/TVnorm.m:2; SALSA/diffh.m, diffv.m, conv2c.m). out[batch]. */
+int sbtv_TVnorm(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double *out, int flags);
+
+/* ---- a-3/a-4: circular blur operator from PSF taps ----------------------
+ * The reference builds A, AT, dA/dp, invLS as FFT closures over
+ * resize(h) = fft2 of the taille x taille taps zero-padded into the TOP-LEFT
+ * corner (utils/resize.m:1-12; run_Gaussian_demo.m:126-139,224-225).  Here a
+ * PSF is its taps (column-major taille x taille, taille <= 15, per image).
+ *
+ * sbtv_A_wrapper replaces A_wrapper(A,AT,x,M1,N1,M2,N2,mode) (SALSA/A_wrapper.m:5-17)
+ * for the closures of the demos:
+ *   mode 1: A x   = real(ifft2( H        .* fft2(x)))      run_Gaussian_demo.m:136
+ *   mode 2: AT x  = real(ifft2( conj(H)  .* fft2(x)))      run_Gaussian_demo.m:137
+ *   mode 3: dA x  = same as mode 1 (pass the derivative taps)   :138-139
+ *   mode 9: invLS = real(ifft2( fft2(x) ./ (abs(H).^2 + mu)))   :224-225
+ * other modes -> SBTV_ERR_MODE.  Each call bumps the call counter by `batch`.
+ */
+int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *mu,
+                   const double *x, double *out, int M, int N, int batch, int mode, int flags);
+
+/* PSF tap builders (host arithmetic, exactly the reference formulas).
+ * kind 0 gaussian  p = {w1, w2, phi}  utils/Gaussian_psf.m:2-19, Sum_gauss_psf.m, diff_fftgaus_w1/w2.m
+ * kind 1 moffat    p = {alpha, beta}  utils/psf_moffat.m:2-20, sum_mof_psf.m, diff_moffat_alpha/beta.m
+ * kind 2 laplace   p = {b}            utils/psf_laplace.m:1-13, sum_lap_psf.m, diff_laplace_b.m
+ * taps, d0, d1: taille*taille doubles (column-major); d0/d1 may be NULL. */
+#define SBTV_PSF_GAUSSIAN 0
+#define SBTV_PSF_MOFFAT   1
+#define SBTV_PSF_LAPLACE  2
+int sbtv_psf_taps(int kind, int taille, const double *p, double *taps, double *d0, double *d1);
+
+/* Packed half-spectrum of a real image (debug / test entry for the FFT
+ * kernels): out is (M/2) x N complex, column-major, interleaved re/im; row 0
+ * holds X[0,l] + i*X[M/2,l].  inverse=1 maps it back (scaled like ifft2). */
+int sbtv_rfft2_packed(sbtv_ctx *ctx, const double *in, double *out, int M, int N, int batch,
+                      int inverse, int flags);
+
+/* ---- a-7: SALSA_v2 -------------------------------------------------------
+ * Replaces  [x,numA,numAt,objective,distance,times,mses] = SALSA_v2(y,A,tau,
+ *   'MU',mu,'AT',AT,'StopCriterion',c,'True_x',x,'ToleranceA',tol,'MAXITERA',n,
+ *   'TVINITIALIZATION',1,'TViters',k,'LS',invLS,...)   (SALSA/SALSA_v2.m:156-494)
+ * with A/AT/invLS the FFT closures defined by `taps` (run_Gaussian_demo.m:215-242).
+ * Only the TV path ('TVINITIALIZATION' = 1) exists: like the reference (:318-320,
+ * quirk Q7) user Psi/Phi are ignored in that mode.
+ */
+typedef struct sbtv_salsa_opts {
+    int    stopcriterion;    /* 1,2,3  (SALSA_v2.m:245-247,456-469)                 */
+    int    maxiter;          /* 'MAXITERA'  default 10000 (:173)                    */
+    int    TViters;          /* 'TVITERS'   default 5 (:181)                        */
+    int    initialization;   /* 0 zeros (:369), 2 AT*y (:373), 33333 x_init given   */
+    int    compute_mse;      /* 1 when 'TRUE_X' given (:227-229)                    */
+    int    speculate;        /* 0: host checks the stop rule every outer iteration  */
+    double tolA;             /* 'TOLERANCEA' default 1e-3 (:178)                    */
+    double chambolle_tol;    /* 1e-3  (chambolle_prox_TV_stop.m:78)                 */
+    double chambolle_tau;    /* 0.249 (chambolle_prox_TV_stop.m:77)                 */
+} sbtv_salsa_opts;
+
+void sbtv_salsa_opts_default(sbtv_salsa_opts *o);
+
+/*   y, true_x, x_init, x_out : M*N*batch images (true_x / x_init may be NULL)
+ *   taps[batch*taille^2], tau[batch], mu[batch]            (host arrays)
+ *   objective[batch*(maxiter+1)], distance[batch*maxiter], times[batch*(maxiter+1)],
+ *   mses[batch*(maxiter+1)]  (host arrays, any may be NULL; row b starts at b*(maxiter+1)
+ *   resp. b*maxiter);  numA, numAt, n_outer: [batch] (host, may be NULL)
+ *   Images in a batch iterate in lock-step; an image that met its stop rule is
+ *   frozen (its x no longer changes) while the others continue. */
+int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
+                  const double *taps, int taille, const double *tau, const double *mu,
+                  const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                  double *x_out, double *objective, double *distance, double *times, double *mses,
+                  int *numA, int *numAt, int *n_outer, int flags);
+
+/* ---- a-8: FISTA with the TV prox ----------------------------------------
+ * Replaces my_fista(b,A,AT,tau,L,Phi,Psi,stopcriterion,tolerance,maxiters,true,verbose)
+ * (SALSA/my_fista.m:5-56) with Psi = cold-start Chambolle(prox_iters) and Phi = TVnorm
+ * (run_moffat_demo.m:181-182), and my_deblur_fista (SALSA/my_deblur_fista.m:5-68) when
+ * zero_start = 1 and L = 1.  objective/mses: [batch*maxiters]; n_iter[batch]. */
+int sbtv_fista_tv(sbtv_ctx *ctx, const double *b, int M, int N, int batch,
+                  const double *taps, int taille, const double *tau, double L,
+                  int prox_iters, int stopcriterion, double tolerance, int maxiters,
+                  int zero_start, const double *true_x, double *x_out,
+                  double *objective, double *mses, int *n_iter, int flags);
+
+/* ---- a-5/a-6: SAPG (MYULA) parameter estimation ---------------------------
+ * Replaces SAPG_algorithm_Guassian / _moffat / _laplace (SAPG/ directory) for `batch`
+ * independent chains.  One chain = one image y_b with its own state.  */
+typedef struct sbtv_sapg_opts {
+    int    kind;              /* SBTV_PSF_*                                              */
+    int    psf_size;          /* 7                                                       */
+    int    samples;           /* op.samples  (total_iter)                                */
+    int    warmup;            /* op.warmup                                               */
+    int    burnIn;            /* op.burnIn (1-based like the reference)                  */
+    int    chambolleit;       /* 25 (run_Gaussian_demo.m:188)                            */
+    int    fix_p[2];          /* op.fix_w1/op.fix_w2 (alpha/beta, b)                     */
+    int    fix_sigma;
+    int    share_gradients;   /* 0: independent chains. 1: all chains sample one image and
+                                 average their gradients (the reference's vestigial
+                                 `for jj=1:1 ... mean(g_*)`, SAPG_algorithm_moffat.m:158-173) */
+    double lambda, gamma;     /* c.lam*op.lambda, c.gam*op.gamma                         */
+    double th_init, min_th, max_th;
+    double p_init[2], p_min[2], p_max[2], p_true[2], phi;
+    double sigma2_init, sigma2_min, sigma2_max, sigma2_true;
+    double d_scale, d_exp;    /* delta(i) = d_scale * i^-d_exp / dimX                    */
+    double c_theta, c_p[2], c_sigma;
+    unsigned long long seed;  /* Philox seed when noise == NULL                          */
+} sbtv_sapg_opts;
+
+/*   y: M*N*batch;  x0: start images (NULL -> y, SAPG_algorithm_Guassian.m:10-12)
+ *   noise: NULL (device Philox randn) or host/device array with
+ *          (warmup-1 + samples-1) * batch * M*N doubles, step-major, consumed
+ *          in the reference's order (warm-up first)
+ *   traces (host, may be NULL): thetas, sigmas [batch*samples]; ps [batch*2*samples];
+ *          logpi [batch*samples]; logpi_wu [batch*warmup]; gx [batch*samples]; grads [batch*4*samples]
+ *   eb[batch*4] : theta_EB, p0_EB, p1_EB, sigma2_EB ;  x_last: last sample (may be NULL)
+ *   reduce_fn: when share_gradients=1 and the chains are spread over several
+ *          processes, called once per iteration with (user, buf, n) to SUM buf[n]
+ *          across processes in place (e.g. an RCCL all-reduce); may be NULL. */
+typedef int (*sbtv_allreduce_fn)(void *user, double *buf, int n);
+int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
+                        const sbtv_sapg_opts *op, const double *x0, const double *noise,
+                        double *thetas, double *ps, double *sigmas, double *logpi,
+                        double *logpi_wu, double *gx, double *grads, double *eb,
+                        double *x_last, sbtv_allreduce_fn reduce_fn, void *reduce_user, int flags);
+
+/* ---- a-9: largest eigenvalue of A'A by power iteration --------------------
+ * Replaces max_eigenval(A,At,params,im_size,tol,max_iter,verbose)
+ * (utils/max_eigenval_Gaussian_Moffat.m:1-27, max_eigenval_Laplace.m:1-28).
+ * x0: start vector (the reference draws randn; MATLAB's stream is unpinned). */
+int sbtv_max_eigenval(sbtv_ctx *ctx, const double *taps, int taille, const double *x0,
+                      int M, int N, double tol, int max_iter, double *val, int *iters, int flags);
+
+/* ---- a-10: metrics ----------------------------------------------------------
+ * sbtv_PSNR: utils/PSNR.m:2-4 ; sbtv_MSE: utils/MSE.m:1-4 (dB). out[batch]. */
+int sbtv_PSNR(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags);
+int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBTV_H */

@@ -1,0 +1,342 @@
+// Context, workspaces, staging, twiddle tables and the host-side PSF tap builders.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "sbtv_internal.h"
+
+namespace sbtv {
+
+static std::string g_error;
+static std::mutex g_error_mu;
+
+void set_global_error(const std::string &msg) {
+    std::lock_guard<std::mutex> lk(g_error_mu);
+    g_error = msg;
+}
+
+int fail(sbtv_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    set_global_error(msg);
+    return code;
+}
+
+int fail_hip(sbtv_ctx *ctx, hipError_t e, const char *what, const char *file, int line) {
+    std::string m = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") at " +
+                    file + ":" + std::to_string(line) + " in " + what;
+    fail(ctx, (int)e > 0 ? (int)e : 999, m);
+    return (int)e > 0 ? (int)e : 999;
+}
+
+int ws_get(sbtv_ctx *ctx, const char *name, size_t bytes, void **out) {
+    DevBuf &b = ctx->ws[name];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SBTV_HIP(ctx, hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        size_t want = (bytes + 255) & ~size_t(255);
+        SBTV_HIP(ctx, hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return 0;
+}
+
+int pinned_get(sbtv_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) {
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SBTV_HIP(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        size_t want = (bytes + 4095) & ~size_t(4095);
+        SBTV_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return 0;
+}
+
+// exp(-2 pi i k / n) with octant symmetry so that the exactly representable
+// values (1, -i, -1, i, and the +-sqrt(1/2) pairs) are exact / symmetric.
+static void unit_root(int k, int n, double *re, double *im) {
+    // angle = -2 pi k / n, reduce k into [0, n)
+    k %= n;
+    if (k < 0) k += n;
+    // use long double evaluation on the first octant
+    auto eval = [&](long long kk, long double *c, long double *s) {
+        // 0 <= kk <= n/8
+        long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)kk / (long double)n;
+        *c = cosl(a);
+        *s = sinl(a);
+    };
+    long long k8 = (long long)k * 8;
+    int oct = (int)(k8 / n);          // octant 0..7 (angle = k/n turns)
+    long double c, s;
+    long long kk = k;
+    switch (oct) {
+        case 0: eval(kk, &c, &s); break;                                                  // a
+        case 1: { long double cc, ss; eval((long long)n / 4 - kk, &cc, &ss); c = ss; s = cc; } break;      // pi/2 - a'
+        case 2: { long double cc, ss; eval(kk - (long long)n / 4, &cc, &ss); c = -ss; s = cc; } break;     // pi/2 + a'
+        case 3: { long double cc, ss; eval((long long)n / 2 - kk, &cc, &ss); c = -cc; s = ss; } break;     // pi - a'
+        case 4: { long double cc, ss; eval(kk - (long long)n / 2, &cc, &ss); c = -cc; s = -ss; } break;    // pi + a'
+        case 5: { long double cc, ss; eval(3 * (long long)n / 4 - kk, &cc, &ss); c = -ss; s = -cc; } break; // 3pi/2 - a'
+        case 6: { long double cc, ss; eval(kk - 3 * (long long)n / 4, &cc, &ss); c = ss; s = -cc; } break; // 3pi/2 + a'
+        default: { long double cc, ss; eval((long long)n - kk, &cc, &ss); c = cc; s = -ss; } break;        // 2pi - a'
+    }
+    *re = (double)c;
+    *im = (double)(-s);   // exp(-i a) = cos a - i sin a
+}
+
+int twiddle_get(sbtv_ctx *ctx, int n, const double2 **out) {
+    auto it = ctx->twiddles.find(n);
+    if (it != ctx->twiddles.end()) {
+        *out = it->second;
+        return 0;
+    }
+    std::vector<double2> h(n);
+    for (int k = 0; k < n; ++k) {
+        if (n >= 8 && n % 8 == 0) {
+            unit_root(k, n, &h[k].x, &h[k].y);
+        } else {
+            long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+            h[k].x = (double)cosl(a);
+            h[k].y = (double)(-sinl(a));
+        }
+    }
+    double2 *d = nullptr;
+    SBTV_HIP(ctx, hipMalloc((void **)&d, sizeof(double2) * (size_t)n));
+    SBTV_HIP(ctx, hipMemcpy(d, h.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
+    ctx->twiddles[n] = d;
+    *out = d;
+    return 0;
+}
+
+int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int flags, const double **dev) {
+    if (p == nullptr) {
+        *dev = nullptr;
+        return 0;
+    }
+    if (flags & SBTV_DEVICE_PTRS) {
+        *dev = p;
+        return 0;
+    }
+    double *d = nullptr;
+    SBTV_TRY(ws_get_t(ctx, name, count, &d));
+    SBTV_HIP(ctx, hipMemcpyAsync(d, p, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return 0;
+}
+
+int stage_out_buf(sbtv_ctx *ctx, const char *name, double *p, size_t count, int flags, double **dev) {
+    if (p != nullptr && (flags & SBTV_DEVICE_PTRS)) {
+        *dev = p;
+        return 0;
+    }
+    // host destination (or no destination at all): internal buffer
+    return ws_get_t(ctx, name, count, dev);
+}
+
+int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count, int flags) {
+    if (host == nullptr || (flags & SBTV_DEVICE_PTRS)) return 0;
+    SBTV_HIP(ctx, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+int sbtv_version(void) { return SBTV_VERSION; }
+
+const char *sbtv_last_error(const sbtv_ctx *ctx) {
+    if (ctx) return ctx->err.c_str();
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(g_error_mu);
+    copy = g_error;
+    return copy.c_str();
+}
+
+int sbtv_ctx_create(int device, sbtv_ctx **out) {
+    if (!out) return fail(nullptr, SBTV_ERR_BADARG, "sbtv_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SBTV_ERR_NODEVICE,
+                    "sbtv_ctx_create: no HIP device visible; libsbtv has no CPU fallback");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, SBTV_ERR_NODEVICE, "sbtv_ctx_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, SBTV_ERR_NODEVICE, "sbtv_ctx_create: cannot query device");
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(nullptr, SBTV_ERR_NODEVICE,
+                    std::string("sbtv_ctx_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    sbtv_ctx *ctx = new sbtv_ctx();
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
+    SBTV_HIP(ctx, hipSetDevice(device));
+    SBTV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (auto &ev : ctx->ev) SBTV_HIP(ctx, hipEventCreate(&ev));
+    *out = ctx;
+    return 0;
+}
+
+int sbtv_ctx_destroy(sbtv_ctx *ctx) {
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->ws)
+        if (kv.second.p) hipFree(kv.second.p);
+    for (auto &kv : ctx->twiddles) hipFree(kv.second);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    for (auto &ev : ctx->ev)
+        if (ev) hipEventDestroy(ev);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int sbtv_ctx_set_stream(sbtv_ctx *ctx, void *hip_stream) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hip_stream == nullptr) {
+        if (!ctx->own_stream) {
+            SBTV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            ctx->own_stream = true;
+        }
+        return 0;
+    }
+    if (ctx->own_stream && ctx->stream) SBTV_HIP(ctx, hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return 0;
+}
+
+int sbtv_ctx_sync(sbtv_ctx *ctx) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sbtv_callcounter_get(const sbtv_ctx *ctx, long long *calls) {
+    if (!ctx || !calls) return SBTV_ERR_BADARG;
+    *calls = ctx->calls;
+    return 0;
+}
+
+int sbtv_callcounter_reset(sbtv_ctx *ctx) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    ctx->calls = 0;
+    return 0;
+}
+
+int sbtv_last_timing(const sbtv_ctx *ctx, double out[4]) {
+    if (!ctx || !out) return SBTV_ERR_BADARG;
+    for (int i = 0; i < 4; ++i) out[i] = ctx->timing[i];
+    return 0;
+}
+
+int sbtv_malloc(sbtv_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    SBTV_HIP(ctx, hipMalloc(dptr, bytes));
+    return 0;
+}
+
+int sbtv_free(sbtv_ctx *ctx, void *dptr) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SBTV_HIP(ctx, hipFree(dptr));
+    return 0;
+}
+
+int sbtv_memcpy_h2d(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sbtv_memcpy_d2h(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// PSF taps (host, double) — formulas of utils/*.m, column-major taille x taille.
+// Element (ii,jj) (0-based) at taps[jj*taille + ii].
+// ---------------------------------------------------------------------------
+int sbtv_psf_taps(int kind, int taille, const double *p, double *taps, double *d0, double *d1) {
+    if (taille < 1 || taille > 15 || !p || !taps)
+        return fail(nullptr, SBTV_ERR_PSF, "sbtv_psf_taps: bad arguments (1 <= taille <= 15)");
+    const int t = taille;
+    const double center = (t + 1) / 2.0;
+    std::vector<double> X(t);
+    for (int i = 0; i < t; ++i) X[i] = (-t + center) + i;   // -taille+center : taille-center
+    const double PI = 3.14159265358979323846;
+    std::vector<double> f(t * t), e0(t * t, 0.0), e1(t * t, 0.0);
+    double s = 0, s0 = 0, s1 = 0;
+    if (kind == SBTV_PSF_GAUSSIAN) {
+        // utils/Gaussian_psf.m:2-19 ; Sum_gauss_psf.m:1-28 ; diff_fftgaus_w1.m / w2.m
+        const double w1 = p[0], w2 = p[1], phi = p[2];
+        for (int jj = 0; jj < t; ++jj)
+            for (int ii = 0; ii < t; ++ii) {
+                const double v = X[ii], u = X[jj];   // ndgrid: v rows, u columns
+                const double U = u * cos(phi) - v * sin(phi);
+                const double V = u * sin(phi) + v * cos(phi);
+                const double c = w1 * w1 * (U * U) + w2 * w2 * (V * V);
+                const double ex = exp(-c / 2);
+                const int q = jj * t + ii;
+                f[q] = ((w1 * w2) / (2 * PI)) * ex;
+                e0[q] = (w2 / (2 * PI)) * (1 - w1 * w1 * (U * U)) * ex;
+                e1[q] = (w1 / (2 * PI)) * (1 - w2 * w2 * (V * V)) * ex;
+            }
+    } else if (kind == SBTV_PSF_MOFFAT) {
+        // utils/psf_moffat.m:2-20 ; sum_mof_psf.m:1-40 ; diff_moffat_alpha.m ; diff_moffat_beta.m
+        const double a = p[0], b = p[1], b2 = b + 2;
+        for (int jj = 0; jj < t; ++jj)
+            for (int ii = 0; ii < t; ++ii) {
+                const double xy = X[ii] * X[ii] + X[jj] * X[jj];
+                const int q = jj * t + ii;
+                f[q] = a * a * pow((xy * (a * a)) / b + 1, -b2 / 2) / (2 * PI);
+                e0[q] = (2 - (((b + 2) * xy * (a * a)) / (2 * (b + xy * (a * a))))) *
+                        pow(1 + xy * (a * a) / b, -(b + 2) / 2) * (a / (2 * PI));
+                const double cons1 = (a * a) / (4 * PI);
+                e1[q] = (-log(xy * (a * a) / b + 1) + (b2 * xy * (a * a)) / (b * (b + xy * (a * a)))) *
+                        pow(xy * (a * a) / b + 1, -b2 / 2) * cons1;
+            }
+    } else if (kind == SBTV_PSF_LAPLACE) {
+        // utils/psf_laplace.m:1-13 ; sum_lap_psf.m:1-28 ; diff_laplace_b.m:1-19
+        const double b = p[0];
+        for (int jj = 0; jj < t; ++jj)
+            for (int ii = 0; ii < t; ++ii) {
+                const double sa = fabs(X[ii]) + fabs(X[jj]);
+                const int q = jj * t + ii;
+                f[q] = ((b * b) / 4) * exp(-b * sa);
+                e0[q] = ((2 * b - (b * b) * sa) / 4) * exp(-b * sa);
+            }
+    } else {
+        return fail(nullptr, SBTV_ERR_PSF, "sbtv_psf_taps: unknown PSF kind");
+    }
+    // MATLAB sum(sum(.)) / sum(k(:)) : column-major accumulation order
+    for (int q = 0; q < t * t; ++q) { s += f[q]; s0 += e0[q]; s1 += e1[q]; }
+    for (int q = 0; q < t * t; ++q) {
+        taps[q] = f[q] / s;
+        if (d0) d0[q] = (e0[q] * s - f[q] * s0) / (s * s);
+        if (d1) d1[q] = (e1[q] * s - f[q] * s1) / (s * s);
+    }
+    return 0;
+}
+
+}  // extern "C"

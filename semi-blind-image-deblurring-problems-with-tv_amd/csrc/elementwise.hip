@@ -1,0 +1,283 @@
+// Fused element-wise passes (K4) of the SALSA / FISTA / MYULA iterations, the
+// scalar collectors and the metrics.  Every pass is 16-byte-per-lane
+// vectorised (images have an even number of elements) and every reduction is a
+// fixed-order two-level sum (per-block partials -> one block per quantity).
+#include "sbtv_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace sbtv {
+
+constexpr int EWB = 256;
+
+__device__ __forceinline__ double ew_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block reduce NQ quantities; thread 0 gets the totals
+template <int NQ>
+__device__ __forceinline__ void ew_block_sum(double (&v)[NQ], double *red /*[NQ*4]*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        const double a = ew_wave_sum(v[c]);
+        if (lane == 0) red[c * 4 + w] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) v[c] = (red[c * 4] + red[c * 4 + 1]) + (red[c * 4 + 2] + red[c * 4 + 3]);
+    }
+}
+
+int ew_blocks(size_t P) {
+    size_t nb = (P / 2 + EWB - 1) / EWB;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// ---- SALSA: bu += u - x ; g = x - bu ; sums for mse / distance / criterion 2
+// (SALSA/SALSA_v2.m:440,446-451,461) ; also forms the next prox input
+// real(PTx - bu) (:429).  partials: [batch][5][nb]
+__global__ __launch_bounds__(EWB) void salsa_post_kernel(const double *__restrict__ xn, double *__restrict__ x,
+                                                          const double *__restrict__ u, double *__restrict__ bu,
+                                                          double *__restrict__ g, const double *__restrict__ tru,
+                                                          double *__restrict__ partials, size_t P,
+                                                          const int *__restrict__ frozen, int copy_x) {
+    const int b = blockIdx.y;
+    if (frozen && frozen[b]) return;
+    __shared__ double red[5 * 4];
+    const size_t base = (size_t)b * P;
+    double acc[5] = {0, 0, 0, 0, 0};
+    const size_t P2 = P / 2;
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P2; q += (size_t)gridDim.x * EWB) {
+        const size_t o = base + 2 * q;
+        const double2 xv = *reinterpret_cast<const double2 *>(xn + o);
+        const double2 uv = *reinterpret_cast<const double2 *>(u + o);
+        double2 bv = *reinterpret_cast<const double2 *>(bu + o);
+        bv.x = bv.x + (uv.x - xv.x);
+        bv.y = bv.y + (uv.y - xv.y);
+        *reinterpret_cast<double2 *>(bu + o) = bv;
+        *reinterpret_cast<double2 *>(g + o) = make_double2(xv.x - bv.x, xv.y - bv.y);
+        if (tru) {
+            const double2 tv = *reinterpret_cast<const double2 *>(tru + o);
+            const double e0 = xv.x - tv.x, e1 = xv.y - tv.y;
+            acc[0] += e0 * e0 + e1 * e1;
+        }
+        {
+            const double d0 = xv.x - uv.x, d1 = xv.y - uv.y;
+            acc[1] += d0 * d0 + d1 * d1;
+            acc[2] += xv.x * xv.x + xv.y * xv.y;
+            acc[3] += uv.x * uv.x + uv.y * uv.y;
+        }
+        if (copy_x) {
+            const double2 xo = *reinterpret_cast<const double2 *>(x + o);
+            const double d0 = xv.x - xo.x, d1 = xv.y - xo.y;
+            acc[4] += d0 * d0 + d1 * d1;
+            *reinterpret_cast<double2 *>(x + o) = xv;
+        }
+    }
+    ew_block_sum<5>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) partials[((size_t)b * 5 + c) * gridDim.x + blockIdx.x] = acc[c];
+    }
+}
+
+// generic two-array sums: partials[b][4][nb] = sum (a-b)^2, sum a^2, sum b^2, max a
+__global__ __launch_bounds__(EWB) void pair_sums_kernel(const double *__restrict__ a, const double *__restrict__ c,
+                                                         double *__restrict__ partials, size_t P) {
+    const int b = blockIdx.y;
+    __shared__ double red[3 * 4];
+    __shared__ double redm[4];
+    const size_t base = (size_t)b * P;
+    double acc[3] = {0, 0, 0};
+    double mx = -1.0e308;
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P; q += (size_t)gridDim.x * EWB) {
+        const double av = a[base + q];
+        const double cv = c ? c[base + q] : 0.0;
+        const double d = av - cv;
+        acc[0] += d * d;
+        acc[1] += av * av;
+        acc[2] += cv * cv;
+        mx = fmax(mx, av);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+    ew_block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 3; ++q) partials[((size_t)b * 4 + q) * gridDim.x + blockIdx.x] = acc[q];
+        partials[((size_t)b * 4 + 3) * gridDim.x + blockIdx.x] = fmax(fmax(redm[0], redm[1]), fmax(redm[2], redm[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_max_kernel(const double *__restrict__ partials, int n,
+                                                          double *__restrict__ out) {
+    __shared__ double redm[4];
+    const double *p = partials + (size_t)blockIdx.x * n;
+    double mx = -1.0e308;
+    for (int q = threadIdx.x; q < n; q += 256) mx = fmax(mx, p[q]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(redm[0], redm[1]), fmax(redm[2], redm[3]));
+}
+
+// ---- FISTA (SALSA/my_fista.m:25,29)
+//   grad step : y = y - (1/L) * grad
+__global__ __launch_bounds__(EWB) void axpy_kernel(double *__restrict__ y, const double *__restrict__ gr, double a,
+                                                    size_t Ptot) {
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < Ptot / 2; q += (size_t)gridDim.x * EWB) {
+        double2 yv = *reinterpret_cast<double2 *>(y + 2 * q);
+        const double2 gv = *reinterpret_cast<const double2 *>(gr + 2 * q);
+        yv.x = yv.x - a * gv.x;
+        yv.y = yv.y - a * gv.y;
+        *reinterpret_cast<double2 *>(y + 2 * q) = yv;
+    }
+}
+//   momentum  : y = x + c (x - x_old) ; x_old = x ; sums (x-true)^2, (x-x_old)^2, x^2   partials [batch][3][nb]
+__global__ __launch_bounds__(EWB) void fista_momentum_kernel(const double *__restrict__ x, double *__restrict__ xold,
+                                                              double *__restrict__ y, const double *__restrict__ tru,
+                                                              const double *__restrict__ coef,
+                                                              double *__restrict__ partials, size_t P,
+                                                              const int *__restrict__ frozen) {
+    const int b = blockIdx.y;
+    if (frozen && frozen[b]) return;
+    __shared__ double red[3 * 4];
+    const size_t base = (size_t)b * P;
+    const double c = coef[b];
+    double acc[3] = {0, 0, 0};
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P / 2; q += (size_t)gridDim.x * EWB) {
+        const size_t o = base + 2 * q;
+        const double2 xv = *reinterpret_cast<const double2 *>(x + o);
+        const double2 xo = *reinterpret_cast<const double2 *>(xold + o);
+        const double d0 = xv.x - xo.x, d1 = xv.y - xo.y;
+        *reinterpret_cast<double2 *>(y + o) = make_double2(xv.x + c * d0, xv.y + c * d1);
+        *reinterpret_cast<double2 *>(xold + o) = xv;
+        if (tru) {
+            const double2 tv = *reinterpret_cast<const double2 *>(tru + o);
+            const double e0 = xv.x - tv.x, e1 = xv.y - tv.y;
+            acc[0] += e0 * e0 + e1 * e1;
+        }
+        acc[1] += d0 * d0 + d1 * d1;
+        acc[2] += xv.x * xv.x + xv.y * xv.y;
+    }
+    ew_block_sum<3>(acc, red);
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 3; ++q) partials[((size_t)b * 3 + q) * gridDim.x + blockIdx.x] = acc[q];
+}
+
+// ---- MYULA step (SAPG/SAPG_algorithm_Guassian.m:80-81,161):
+//   X = abs( X + gam*(prox - X)/lamb - gam*gradF + sqrt(2 gam) * Z ),  gradF = grad / sigma2
+__global__ __launch_bounds__(EWB) void myula_step_kernel(double *__restrict__ X, const double *__restrict__ prox,
+                                                          const double *__restrict__ grad,
+                                                          const double *__restrict__ Z,
+                                                          const double *__restrict__ sigma2, double gam, double lamb,
+                                                          double sq2g, size_t P) {
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * P;
+    const double s2 = sigma2[b];
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P / 2; q += (size_t)gridDim.x * EWB) {
+        const size_t o = base + 2 * q;
+        const double2 xv = *reinterpret_cast<const double2 *>(X + o);
+        const double2 pv = *reinterpret_cast<const double2 *>(prox + o);
+        const double2 gv = *reinterpret_cast<const double2 *>(grad + o);
+        const double2 zv = *reinterpret_cast<const double2 *>(Z + o);
+        double2 r;
+        r.x = fabs(((xv.x + gam * (pv.x - xv.x) / lamb) - gam * (gv.x / s2)) + sq2g * zv.x);
+        r.y = fabs(((xv.y + gam * (pv.y - xv.y) / lamb) - gam * (gv.y / s2)) + sq2g * zv.y);
+        *reinterpret_cast<double2 *>(X + o) = r;
+    }
+}
+
+// --------------------------------------------------------------------------
+// host wrappers
+// --------------------------------------------------------------------------
+int salsa_post(sbtv_ctx *ctx, const double *xn, double *x, const double *u, double *bu, double *g, const double *tru,
+               double *partials, size_t P, int batch, const int *frozen, int copy_x) {
+    hipLaunchKernelGGL(salsa_post_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, xn, x, u, bu, g, tru,
+                       partials, P, frozen, copy_x);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev) {
+    const int nb = ew_blocks(P);
+    double *partials = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "ew.pair.partials", (size_t)batch * 4 * nb, &partials));
+    hipLaunchKernelGGL(pair_sums_kernel, dim3(nb, batch), dim3(EWB), 0, ctx->stream, a, c, partials, P);
+    SBTV_HIP(ctx, hipGetLastError());
+    // sums: vectors (b,0..2); max: vector (b,3)
+    for (int b = 0; b < batch; ++b) {
+        SBTV_TRY(reduce_partials(ctx, partials + (size_t)b * 4 * nb, 3, nb, out4_dev + (size_t)b * 4));
+        hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, ctx->stream, partials + ((size_t)b * 4 + 3) * nb,
+                           nb, out4_dev + (size_t)b * 4 + 3);
+    }
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(Ptot)), dim3(EWB), 0, ctx->stream, y, gr, a, Ptot);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, const double *coef_dev,
+                   double *partials, size_t P, int batch, const int *frozen) {
+    hipLaunchKernelGGL(fista_momentum_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, x, xold, y, tru,
+                       coef_dev, partials, P, frozen);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
+               const double *sigma2_dev, double gam, double lamb, size_t P, int batch) {
+    hipLaunchKernelGGL(myula_step_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, X, prox, grad, Z,
+                       sigma2_dev, gam, lamb, sqrt(2 * gam), P);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+static int metric_common(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out,
+                         int flags, bool psnr) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    if (!x_true || !x || !out || M < 1 || N < 1 || batch < 1) return fail(ctx, SBTV_ERR_BADARG, "metric: bad arguments");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)M * N;
+    const double *a = nullptr, *c = nullptr;
+    SBTV_TRY(stage_in(ctx, "metric.a", x_true, P * batch, flags, &a));
+    SBTV_TRY(stage_in(ctx, "metric.c", x, P * batch, flags, &c));
+    double *o4 = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "metric.out", (size_t)batch * 4, &o4));
+    SBTV_TRY(pair_sums(ctx, a, c, P, batch, o4));
+    std::vector<double> h((size_t)batch * 4);
+    SBTV_HIP(ctx, hipMemcpyAsync(h.data(), o4, sizeof(double) * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < batch; ++b) {
+        const double se = h[(size_t)b * 4], mx = h[(size_t)b * 4 + 3];
+        if (psnr)
+            out[b] = 10 * log10(mx * mx) - 10 * log10(se / (double)P);   // utils/PSNR.m:3-4
+        else
+            out[b] = 10 * log10(se / (double)P);                          // utils/MSE.m:3
+    }
+    return 0;
+}
+
+int sbtv_PSNR(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags) {
+    return metric_common(ctx, x_true, x, M, N, batch, out, flags, true);
+}
+int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags) {
+    return metric_common(ctx, x_true, x, M, N, batch, out, flags, false);
+}
+
+}  // extern "C"

@@ -1,0 +1,746 @@
+// Batched 2-D real FFT / IFFT and the spectral form of the circular blur
+// operator (K5-K8), hand-written for gfx950.  No rocFFT.
+//
+// A real M x N image (column-major) is transformed in two passes:
+//   cols : each column (M reals = M/2 complex, contiguous) -> complex FFT of
+//          length n1 = M/2 + the real-input split step.  The result is the
+//          PACKED half spectrum S (n1 x N complex, column-major): row k>=1 is
+//          X[k,:], row 0 holds X[0,:] + i X[M/2,:] (both are real sequences
+//          along the column, so nothing is lost and S has exactly the bytes of
+//          the real image).
+//   rows : each of the n1 spectral rows (stride n1) -> complex FFT of length N.
+//          A workgroup owns RK consecutive rows so a wave reads RK*16-byte
+//          contiguous segments.  The rows kernel optionally applies a spectral
+//          point-wise operator and the inverse row FFT before storing, so that
+//          A, AT, invLS and the fused SALSA / gradient steps need one pass.
+// The 1-D engine is a mixed-radix (8,8,..,{4,2}) Stockham autosort FFT: every
+// thread keeps 8 complex values in registers (elements t + s*n/8), stages are
+// radix-8 butterflies in registers and the inter-stage exchange goes through
+// LDS (real and imaginary planes in turn, padded against bank conflicts).
+// The first stage reads global memory directly in its natural coalesced order
+// and the last stage leaves the result in the same register slots, so global
+// stores are coalesced too.
+#include "sbtv_internal.h"
+
+namespace sbtv {
+
+// ---------------------------------------------------------------------------
+// complex helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {   // a * conj(b)
+    return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ double cabs2(double2 a) { return a.x * a.x + a.y * a.y; }
+
+template <bool INV>
+__device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int idx) {
+    double2 w = tw[idx];
+    if (INV) w.y = -w.y;
+    return w;
+}
+// multiply by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ double2 mul_mi(double2 a) {
+    return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ void bfly2(double2 &a, double2 &b) {
+    const double2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+template <bool INV>
+__device__ __forceinline__ void bfly4(double2 &a0, double2 &a1, double2 &a2, double2 &a3) {
+    const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi<INV>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+template <bool INV>
+__device__ __forceinline__ void bfly8(double2 &a0, double2 &a1, double2 &a2, double2 &a3, double2 &a4, double2 &a5,
+                                      double2 &a6, double2 &a7) {
+    constexpr double R2 = 0.70710678118654752440;
+    bfly4<INV>(a0, a2, a4, a6);   // E[0..3] in a0,a2,a4,a6
+    bfly4<INV>(a1, a3, a5, a7);   // O[0..3] in a1,a3,a5,a7
+    // w8^m * O[m]
+    double2 o1, o3;
+    if (!INV) {
+        o1 = make_double2((a3.x + a3.y) * R2, (a3.y - a3.x) * R2);      // (1-i)/sqrt2
+        o3 = make_double2((a7.y - a7.x) * R2, (-a7.x - a7.y) * R2);     // (-1-i)/sqrt2
+    } else {
+        o1 = make_double2((a3.x - a3.y) * R2, (a3.x + a3.y) * R2);      // (1+i)/sqrt2
+        o3 = make_double2((-a7.x - a7.y) * R2, (a7.x - a7.y) * R2);     // (-1+i)/sqrt2
+    }
+    const double2 o0 = a1, o2 = mul_mi<INV>(a5);
+    const double2 e0 = a0, e1 = a2, e2 = a4, e3 = a6;
+    a0 = cadd(e0, o0);
+    a1 = cadd(e1, o1);
+    a2 = cadd(e2, o2);
+    a3 = cadd(e3, o3);
+    a4 = csub(e0, o0);
+    a5 = csub(e1, o1);
+    a6 = csub(e2, o2);
+    a7 = csub(e3, o3);
+}
+
+template <int LR, bool INV>
+__device__ __forceinline__ void butterflies(double2 (&v)[8]) {
+    if constexpr (LR == 3) {
+        bfly8<INV>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    } else if constexpr (LR == 2) {
+        bfly4<INV>(v[0], v[2], v[4], v[6]);
+        bfly4<INV>(v[1], v[3], v[5], v[7]);
+    } else {
+        bfly2<INV>(v[0], v[4]);
+        bfly2<INV>(v[1], v[5]);
+        bfly2<INV>(v[2], v[6]);
+        bfly2<INV>(v[3], v[7]);
+    }
+}
+
+// twiddles of a Stockham stage: element r of the butterfly at j gets
+// exp(-+2 pi i r (j mod Ns) / (Ns R))
+template <int LOG2N, int LOG2NS, int LR, bool INV>
+__device__ __forceinline__ void apply_twiddles(double2 (&v)[8], int t, const double2 *__restrict__ tw) {
+    if constexpr (LOG2NS > 0) {
+        constexpr int T = (1 << LOG2N) / 8;
+        constexpr int R = 1 << LR, G = 8 / R;
+        constexpr int SH = LOG2N - LOG2NS - LR;   // log2 of n / (Ns R)
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int k = (t + q * T) & ((1 << LOG2NS) - 1);
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[q + r * G] = cmul(v[q + r * G], twid<INV>(tw, (r * k) << SH));
+        }
+    }
+}
+
+// LDS exchange accessors ------------------------------------------------------
+// Column kernels: each sequence has its own padded region, t is the fast lane index.
+struct ColsX {
+    double *lds;     // base of this sequence's region
+    __device__ __forceinline__ int idx(int pos) const { return pos + (pos >> 3); }
+};
+// Row kernels: RK sequences interleaved (sequence index fastest).
+template <int RK>
+struct RowsX {
+    double *lds;
+    int q;
+    __device__ __forceinline__ int idx(int pos) const {
+        const int i = pos * RK + q;
+        return i + ((i >> 5) << 2);
+    }
+};
+
+// write stage outputs to their Stockham positions, read back elements t + s*T
+template <int LOG2N, int LOG2NS, int LR, class X>
+__device__ __forceinline__ void exchange(double2 (&v)[8], int t, const X &x) {
+    constexpr int T = (1 << LOG2N) / 8;
+    constexpr int R = 1 << LR, G = 8 / R;
+    int pos[8];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        const int j = t + q * T;
+        const int k = j & ((1 << LOG2NS) - 1);
+        const int j0 = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) pos[q + r * G] = x.idx(j0 + (r << LOG2NS));
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x.lds[pos[s]] = v[s].x;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s].x = x.lds[x.idx(t + s * T)];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x.lds[pos[s]] = v[s].y;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s].y = x.lds[x.idx(t + s * T)];
+    __syncthreads();
+}
+
+// mirrored read: out[s] = in[(n - (t+s*T)) mod n]
+template <int LOG2N, class X>
+__device__ __forceinline__ void mirror(const double2 (&v)[8], double2 (&m)[8], int t, const X &x) {
+    constexpr int n = 1 << LOG2N, T = n / 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x.lds[x.idx(t + s * T)] = v[s].x;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) m[s].x = x.lds[x.idx((n - (t + s * T)) & (n - 1))];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x.lds[x.idx(t + s * T)] = v[s].y;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) m[s].y = x.lds[x.idx((n - (t + s * T)) & (n - 1))];
+    __syncthreads();
+}
+
+template <int LOG2N, int LOG2NS, bool INV, class X>
+__device__ __forceinline__ void fft_stages(double2 (&v)[8], int t, const double2 *__restrict__ tw, const X &x) {
+    constexpr int left = LOG2N - LOG2NS;
+    if constexpr (left > 0) {
+        constexpr int LR = left >= 3 ? 3 : left;
+        apply_twiddles<LOG2N, LOG2NS, LR, INV>(v, t, tw);
+        butterflies<LR, INV>(v);
+        if constexpr (left - LR > 0) {
+            exchange<LOG2N, LOG2NS, LR>(v, t, x);
+            fft_stages<LOG2N, LOG2NS + LR, INV>(v, t, tw, x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// column pass, forward: real columns -> packed half spectrum
+// ---------------------------------------------------------------------------
+constexpr int COLS_THREADS = 256;
+
+template <int LOG2N>   // n1 = M/2 = 1 << LOG2N
+__global__ __launch_bounds__(COLS_THREADS) void fft_cols_fwd_kernel(const double *__restrict__ x,
+                                                                     const double *__restrict__ add,
+                                                                     double2 *__restrict__ S,
+                                                                     const double2 *__restrict__ tw_n1,
+                                                                     const double2 *__restrict__ tw_M, int N,
+                                                                     const int *__restrict__ frozen) {
+    constexpr int n = 1 << LOG2N, T = n / 8;
+    constexpr int LDSN = n + (n >> 3);
+    constexpr int MAXSEQ = (COLS_THREADS / T) > 0 ? (COLS_THREADS / T) : 1;
+    __shared__ double lds[MAXSEQ * LDSN];
+    const int b = blockIdx.y;
+    if (frozen && frozen[b]) return;
+    const int nseq = blockDim.x / T;
+    const int seq = threadIdx.x / T, t = threadIdx.x - seq * T;
+    const int j = blockIdx.x * nseq + seq;          // column (grid is exact: N % nseq == 0)
+    const size_t colbase = ((size_t)b * N + j) * n;  // in complex elements
+    const double2 *__restrict__ xin = reinterpret_cast<const double2 *>(x) + colbase;
+    ColsX X{lds + seq * LDSN};
+    double2 v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = xin[t + s * T];
+    if (add) {
+        const double2 *__restrict__ ain = reinterpret_cast<const double2 *>(add) + colbase;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[s] = cadd(v[s], ain[t + s * T]);
+    }
+    fft_stages<LOG2N, 0, false>(v, t, tw_n1, X);
+    double2 m[8];
+    mirror<LOG2N>(v, m, t, X);
+    double2 *__restrict__ out = S + colbase;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int e = t + s * T;
+        const double2 Z = v[s], Zm = cconj(m[s]);
+        double2 r;
+        if (e == 0) {
+            r = make_double2(Z.x + Z.y, Z.x - Z.y);          // X[0] + i X[M/2]
+        } else {
+            const double2 w = tw_M[e];
+            const double2 su = cadd(Z, Zm), di = csub(Z, Zm);
+            const double2 wd = cmul(w, di);                  // w (Z - Zm)
+            // X = 1/2 su - i/2 wd
+            r = make_double2(0.5 * (su.x + wd.y), 0.5 * (su.y - wd.x));
+        }
+        out[e] = r;
+    }
+}
+
+// column pass, inverse: packed half spectrum -> real columns (times `scale`)
+template <int LOG2N>
+__global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double2 *__restrict__ S,
+                                                                     double *__restrict__ x,
+                                                                     const double2 *__restrict__ tw_n1,
+                                                                     const double2 *__restrict__ tw_M, int N,
+                                                                     double scale, const int *__restrict__ frozen) {
+    constexpr int n = 1 << LOG2N, T = n / 8;
+    constexpr int LDSN = n + (n >> 3);
+    constexpr int MAXSEQ = (COLS_THREADS / T) > 0 ? (COLS_THREADS / T) : 1;
+    __shared__ double lds[MAXSEQ * LDSN];
+    const int b = blockIdx.y;
+    if (frozen && frozen[b]) return;
+    const int nseq = blockDim.x / T;
+    const int seq = threadIdx.x / T, t = threadIdx.x - seq * T;
+    const int j = blockIdx.x * nseq + seq;
+    const size_t colbase = ((size_t)b * N + j) * n;
+    const double2 *__restrict__ in = S + colbase;
+    ColsX X{lds + seq * LDSN};
+    double2 v[8], m[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = in[t + s * T];
+    mirror<LOG2N>(v, m, t, X);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int e = t + s * T;
+        if (e == 0) {
+            const double X0 = v[s].x, Xn = v[s].y;
+            v[s] = make_double2(0.5 * (X0 + Xn), 0.5 * (X0 - Xn));     // E + i O
+        } else {
+            const double2 Xk = v[s], Xm = cconj(m[s]);
+            const double2 E = cscale(cadd(Xk, Xm), 0.5);
+            const double2 O = cmulc(cscale(csub(Xk, Xm), 0.5), tw_M[e]);   // * conj(w_M^e)
+            v[s] = make_double2(E.x - O.y, E.y + O.x);                  // E + i O
+        }
+    }
+    fft_stages<LOG2N, 0, true>(v, t, tw_n1, X);
+    double2 *__restrict__ out = reinterpret_cast<double2 *>(x) + colbase;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) out[t + s * T] = cscale(v[s], scale);
+}
+
+// ---------------------------------------------------------------------------
+// row pass with optional fused spectral operator
+// ---------------------------------------------------------------------------
+struct RowsParams {
+    const double2 *Sin;
+    double2 *Sout;
+    const double2 *tw;      // length N
+    const double2 *H, *Y, *D1, *D2;
+    const double *mu;
+    double *acc;            // [batch][3][nrb]
+    const int *frozen;
+    int n1;                 // rows of S per image
+    int fwd, inv, op;
+};
+
+template <int OP>
+__device__ __forceinline__ double2 spec_apply(double2 V, double2 H, double2 Y, double2 D1, double2 D2, double mu,
+                                              double wgt, double (&acc)[3]) {
+    if constexpr (OP == OP_MUL_H) {
+        return cmul(V, H);
+    } else if constexpr (OP == OP_MUL_HC) {
+        return cmulc(V, H);
+    } else if constexpr (OP == OP_INVLS) {
+        const double d = cabs2(H) + mu;
+        return make_double2(V.x / d, V.y / d);
+    } else if constexpr (OP == OP_ATA) {
+        return cscale(V, cabs2(H));
+    } else if constexpr (OP == OP_SALSA) {
+        const double d = cabs2(H) + mu;
+        const double2 num = cadd(cmulc(Y, H), cscale(V, mu));     // conj(H) Y + mu S
+        const double2 Xh = make_double2(num.x / d, num.y / d);
+        const double2 R = csub(Y, cmul(H, Xh));
+        acc[0] += wgt * cabs2(R);
+        return Xh;
+    } else if constexpr (OP == OP_RESID) {
+        const double2 R = csub(cmul(H, V), Y);
+        acc[0] += wgt * cabs2(R);
+        return V;
+    } else if constexpr (OP == OP_GRADF) {
+        const double2 R = csub(cmul(H, V), Y);
+        acc[0] += wgt * cabs2(R);
+        return cmulc(R, H);
+    } else if constexpr (OP == OP_GRAD) {
+        const double2 R = csub(cmul(H, V), Y);
+        acc[0] += wgt * cabs2(R);
+        const double2 d1 = cmulc(cmul(D1, V), R), d2 = cmulc(cmul(D2, V), R);
+        acc[1] += wgt * d1.x;
+        acc[2] += wgt * d2.x;
+        return cmulc(R, H);                                       // conj(H) R
+    } else {
+        return V;
+    }
+}
+
+template <int LOG2N, int RK, int OP>
+__global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsParams p) {
+    constexpr int N = 1 << LOG2N, T = N / 8;
+    constexpr int LDSI = RK * N;
+    constexpr int LDSN = LDSI + ((LDSI >> 5) << 2) + 8;
+    __shared__ double lds[LDSN];
+    __shared__ double red[3 * 16];
+    const int b = blockIdx.y;
+    if (p.frozen && p.frozen[b]) return;
+    const int q = threadIdx.x % RK, t = threadIdx.x / RK;
+    const int kb = blockIdx.x;
+    const int k = kb * RK + q;
+    const int n1 = p.n1;
+    const size_t ibase = (size_t)b * n1 * N;
+    const double2 *__restrict__ in = p.Sin + ibase;
+    RowsX<RK> X{lds, q};
+    double2 v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = in[(size_t)(t + s * T) * n1 + k];
+    if (p.fwd) fft_stages<LOG2N, 0, false>(v, t, p.tw, X);
+
+    double acc[3] = {0.0, 0.0, 0.0};
+    if constexpr (OP != OP_NONE) {
+        const size_t hbase = (size_t)b * (n1 + 1) * N;
+        const double mu = p.mu ? p.mu[b] : 0.0;
+        constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF);
+        constexpr bool needD = (OP == OP_GRAD);
+        if (kb == 0) {
+            // the block that owns the packed row 0 = X[0,:] + i X[M/2,:]
+            double2 m[8];
+            mirror<LOG2N>(v, m, t, X);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int l = t + s * T;
+                const size_t hi = hbase + (size_t)l * (n1 + 1);
+                if (q == 0) {
+                    const double2 P = v[s], Q = cconj(m[s]);
+                    const double2 A = cscale(cadd(P, Q), 0.5);
+                    const double2 dB = csub(P, Q);
+                    const double2 B = make_double2(0.5 * dB.y, -0.5 * dB.x);   // (P-Q)/(2i)
+                    const double2 z = make_double2(0.0, 0.0);
+                    const double2 A2 = spec_apply<OP>(A, p.H[hi], needY ? p.Y[hi] : z, needD ? p.D1[hi] : z,
+                                                      needD ? p.D2[hi] : z, mu, 1.0, acc);
+                    const double2 B2 = spec_apply<OP>(B, p.H[hi + n1], needY ? p.Y[hi + n1] : z,
+                                                      needD ? p.D1[hi + n1] : z, needD ? p.D2[hi + n1] : z, mu, 1.0,
+                                                      acc);
+                    v[s] = make_double2(A2.x - B2.y, A2.y + B2.x);             // A' + i B'
+                } else {
+                    const double2 z = make_double2(0.0, 0.0);
+                    v[s] = spec_apply<OP>(v[s], p.H[hi + k], needY ? p.Y[hi + k] : z, needD ? p.D1[hi + k] : z,
+                                          needD ? p.D2[hi + k] : z, mu, 2.0, acc);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int l = t + s * T;
+                const size_t hi = hbase + (size_t)l * (n1 + 1) + k;
+                const double2 z = make_double2(0.0, 0.0);
+                v[s] = spec_apply<OP>(v[s], p.H[hi], needY ? p.Y[hi] : z, needD ? p.D1[hi] : z,
+                                      needD ? p.D2[hi] : z, mu, 2.0, acc);
+            }
+        }
+        if constexpr (needY) {
+            // deterministic block reduction of the accumulators
+            constexpr int NT = RK * T;
+            if constexpr (NT >= 64) {
+                const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                constexpr int NW = NT / 64;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double a = acc[c];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+                    if (lane == 0) red[c * 16 + w] = a;
+                }
+                __syncthreads();
+                if (threadIdx.x < 3) {
+                    double a = 0.0;
+                    for (int ww = 0; ww < NW; ++ww) a += red[threadIdx.x * 16 + ww];
+                    p.acc[((size_t)b * 3 + threadIdx.x) * gridDim.x + kb] = a;
+                }
+            } else {
+                // partial wave: go through LDS (the exchange buffer is idle here)
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lds[c * NT + threadIdx.x] = acc[c];
+                __syncthreads();
+                if (threadIdx.x < 3) {
+                    double a = 0.0;
+                    for (int ww = 0; ww < NT; ++ww) a += lds[threadIdx.x * NT + ww];
+                    p.acc[((size_t)b * 3 + threadIdx.x) * gridDim.x + kb] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (p.inv) fft_stages<LOG2N, 0, true>(v, t, p.tw, X);
+    if (p.Sout) {
+        double2 *__restrict__ out = p.Sout + ibase;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) out[(size_t)(t + s * T) * n1 + k] = v[s];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// unpack S -> U ((n1+1) x N, true spectrum rows 0..M/2)
+// ---------------------------------------------------------------------------
+__global__ void spec_unpack_kernel(const double2 *__restrict__ S, double2 *__restrict__ U, int n1, int N) {
+    const int b = blockIdx.z;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;   // 0..n1
+    const int l = blockIdx.y;
+    if (k > n1) return;
+    const double2 *s = S + (size_t)b * n1 * N;
+    double2 *u = U + (size_t)b * (n1 + 1) * N;
+    double2 r;
+    if (k == 0 || k == n1) {
+        const double2 P = s[(size_t)l * n1];
+        const double2 Q = cconj(s[(size_t)((N - l) & (N - 1)) * n1]);
+        if (k == 0) {
+            r = cscale(cadd(P, Q), 0.5);
+        } else {
+            const double2 d = csub(P, Q);
+            r = make_double2(0.5 * d.y, -0.5 * d.x);
+        }
+    } else {
+        r = s[(size_t)l * n1 + k];
+    }
+    u[(size_t)l * (n1 + 1) + k] = r;
+}
+
+// direct DFT of the zero-padded taps (utils/resize.m:1-12): U[k,l] = sum h[m,n] wM^(km) wN^(ln)
+__global__ void psf_spectrum_kernel(const double *__restrict__ taps, int taille, double2 *__restrict__ U, int n1,
+                                    int M, int N, const double2 *__restrict__ tw_M, const double2 *__restrict__ tw_N) {
+    const int b = blockIdx.z;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (k > n1) return;
+    const double *h = taps + (size_t)b * taille * taille;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int nn = 0; nn < taille; ++nn) {
+        double2 c = make_double2(0.0, 0.0);
+        for (int m = 0; m < taille; ++m) {
+            const double2 w = tw_M[(k * m) & (M - 1)];
+            const double hv = h[nn * taille + m];
+            c.x += hv * w.x;
+            c.y += hv * w.y;
+        }
+        acc = cadd(acc, cmul(c, tw_N[(l * nn) & (N - 1)]));
+    }
+    U[(size_t)b * (n1 + 1) * N + (size_t)l * (n1 + 1) + k] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
+    if (!is_pow2(M) || !is_pow2(N) || M < 16 || N < 16 || M > 4096 || N > 2048)
+        return fail(ctx, SBTV_ERR_SIZE, "blur operator: M and N must be powers of two, 16 <= M <= 4096, 16 <= N <= 2048");
+    pl->M = M;
+    pl->N = N;
+    pl->batch = batch;
+    pl->n1 = M / 2;
+    SBTV_TRY(twiddle_get(ctx, pl->n1, &pl->tw_n1));
+    SBTV_TRY(twiddle_get(ctx, M, &pl->tw_M));
+    SBTV_TRY(twiddle_get(ctx, N, &pl->tw_N));
+    return 0;
+}
+
+static inline int cols_nseq(int n1, int N) {
+    const int T = n1 / 8;
+    int nseq = COLS_THREADS / T;
+    if (nseq < 1) nseq = 1;
+    if (nseq > N) nseq = N;
+    return nseq;
+}
+
+template <int L>
+static void launch_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S,
+                            const int *frozen) {
+    const int nseq = cols_nseq(pl.n1, pl.N);
+    hipLaunchKernelGGL(fft_cols_fwd_kernel<L>, dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0, ctx->stream,
+                       x, add, S, pl.tw_n1, pl.tw_M, pl.N, frozen);
+}
+template <int L>
+static void launch_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale,
+                            const int *frozen) {
+    const int nseq = cols_nseq(pl.n1, pl.N);
+    hipLaunchKernelGGL(fft_cols_inv_kernel<L>, dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0, ctx->stream,
+                       S, x, pl.tw_n1, pl.tw_M, pl.N, scale, frozen);
+}
+
+#define SBTV_DISPATCH_LOG2(L, CALL)                                    \
+    switch (L) {                                                       \
+        case 3: CALL(3); break;                                        \
+        case 4: CALL(4); break;                                        \
+        case 5: CALL(5); break;                                        \
+        case 6: CALL(6); break;                                        \
+        case 7: CALL(7); break;                                        \
+        case 8: CALL(8); break;                                        \
+        case 9: CALL(9); break;                                        \
+        case 10: CALL(10); break;                                      \
+        case 11: CALL(11); break;                                      \
+        default: return fail(ctx, SBTV_ERR_SIZE, "unsupported FFT length"); \
+    }
+
+int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S,
+                   const int *frozen) {
+    const int L = ilog2(pl.n1);
+#define CALL(LL) launch_cols_fwd<LL>(ctx, pl, x, add, S, frozen)
+    SBTV_DISPATCH_LOG2(L, CALL)
+#undef CALL
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int fft_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S) {
+    return fft_cols_fwd_f(ctx, pl, x, add, S, nullptr);
+}
+
+int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen) {
+    const int L = ilog2(pl.n1);
+#define CALL(LL) launch_cols_inv<LL>(ctx, pl, S, x, scale, frozen)
+    SBTV_DISPATCH_LOG2(L, CALL)
+#undef CALL
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale) {
+    return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
+}
+
+static inline int rows_rk(int N) { return (N >= 512) ? 4 : 8; }
+int fft_rows_blocks(const FftPlan &pl) { return pl.n1 / rows_rk(pl.N); }
+
+template <int L, int RK>
+static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
+    const dim3 grid(pl.n1 / RK, pl.batch), block(RK * ((1 << L) / 8));
+    switch (p.op) {
+        case OP_NONE: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_NONE>), grid, block, 0, ctx->stream, p); break;
+        case OP_MUL_H: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_MUL_H>), grid, block, 0, ctx->stream, p); break;
+        case OP_MUL_HC: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_MUL_HC>), grid, block, 0, ctx->stream, p); break;
+        case OP_INVLS: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_INVLS>), grid, block, 0, ctx->stream, p); break;
+        case OP_SALSA: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_SALSA>), grid, block, 0, ctx->stream, p); break;
+        case OP_RESID: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_RESID>), grid, block, 0, ctx->stream, p); break;
+        case OP_GRAD: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_GRAD>), grid, block, 0, ctx->stream, p); break;
+        case OP_ATA: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_ATA>), grid, block, 0, ctx->stream, p); break;
+        case OP_GRADF: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_GRADF>), grid, block, 0, ctx->stream, p); break;
+        default: break;
+    }
+}
+
+int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout, const RowsArgs &a) {
+    RowsParams p;
+    p.Sin = Sin;
+    p.Sout = Sout;
+    p.tw = pl.tw_N;
+    p.H = a.H;
+    p.Y = a.Y;
+    p.D1 = a.D1;
+    p.D2 = a.D2;
+    p.mu = a.mu;
+    p.acc = a.acc;
+    p.frozen = a.frozen;
+    p.n1 = pl.n1;
+    p.fwd = a.dir_fwd;
+    p.inv = a.dir_inv;
+    p.op = a.op;
+    const int L = ilog2(pl.N);
+    if (L > 11) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 2048");
+    if (pl.N >= 512) {
+        switch (L) {
+            case 9: launch_rows<9, 4>(ctx, pl, p); break;
+            case 10: launch_rows<10, 4>(ctx, pl, p); break;
+            case 11: launch_rows<11, 4>(ctx, pl, p); break;
+            default: break;
+        }
+    } else {
+        switch (L) {
+            case 4: launch_rows<4, 8>(ctx, pl, p); break;
+            case 5: launch_rows<5, 8>(ctx, pl, p); break;
+            case 6: launch_rows<6, 8>(ctx, pl, p); break;
+            case 7: launch_rows<7, 8>(ctx, pl, p); break;
+            case 8: launch_rows<8, 8>(ctx, pl, p); break;
+            default: return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be >= 16");
+        }
+    }
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U) {
+    const int thr = 64;
+    hipLaunchKernelGGL(spec_unpack_kernel, dim3((pl.n1 + 1 + thr - 1) / thr, pl.N, pl.batch), dim3(thr), 0,
+                       ctx->stream, S, U, pl.n1, pl.N);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U) {
+    const int thr = 64;
+    hipLaunchKernelGGL(psf_spectrum_kernel, dim3((pl.n1 + 1 + thr - 1) / thr, pl.N, pl.batch), dim3(thr), 0,
+                       ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+int sbtv_rfft2_packed(sbtv_ctx *ctx, const double *in, double *out, int M, int N, int batch, int inverse, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    if (!in || !out || batch < 1) return fail(ctx, SBTV_ERR_BADARG, "rfft2_packed: bad arguments");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    FftPlan pl;
+    SBTV_TRY(fft_plan(ctx, M, N, batch, &pl));
+    const size_t cnt = (size_t)M * N * batch;
+    const double *ind = nullptr;
+    double *outd = nullptr;
+    SBTV_TRY(stage_in(ctx, "fft.in", in, cnt, flags, &ind));
+    SBTV_TRY(stage_out_buf(ctx, "fft.out", out, cnt, flags, &outd));
+    double2 *tmp = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "fft.tmp", cnt / 2, &tmp));
+    RowsArgs a{};
+    a.op = OP_NONE;
+    if (!inverse) {
+        SBTV_TRY(fft_cols_fwd(ctx, pl, ind, nullptr, tmp));
+        a.dir_fwd = 1;
+        a.dir_inv = 0;
+        SBTV_TRY(fft_rows(ctx, pl, tmp, reinterpret_cast<double2 *>(outd), a));
+    } else {
+        a.dir_fwd = 0;
+        a.dir_inv = 1;
+        SBTV_TRY(fft_rows(ctx, pl, reinterpret_cast<const double2 *>(ind), tmp, a));
+        SBTV_TRY(fft_cols_inv(ctx, pl, tmp, outd, 1.0 / ((double)pl.n1 * N)));
+    }
+    SBTV_TRY(stage_out_copy(ctx, out, outd, cnt, flags));
+    if (!(flags & SBTV_DEVICE_PTRS)) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *mu, const double *x, double *out,
+                   int M, int N, int batch, int mode, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    int op;
+    switch (mode) {
+        case 1: case 3: op = OP_MUL_H; break;
+        case 2: op = OP_MUL_HC; break;
+        case 9: op = OP_INVLS; break;
+        default: return fail(ctx, SBTV_ERR_MODE, "The value of parameter mode must be 1 or 2 (or 3, 9).");
+    }
+    if (!taps || !x || !out || batch < 1) return fail(ctx, SBTV_ERR_BADARG, "A_wrapper: bad arguments");
+    if (taille < 1 || taille > 15 || taille > M || taille > N)
+        return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
+    if (mode == 9 && !mu) return fail(ctx, SBTV_ERR_MISSING_LS, "A_wrapper: mode 9 (invLS) needs mu");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    FftPlan pl;
+    SBTV_TRY(fft_plan(ctx, M, N, batch, &pl));
+    const size_t cnt = (size_t)M * N * batch;
+    const double *xd = nullptr;
+    double *outd = nullptr;
+    SBTV_TRY(stage_in(ctx, "op.in", x, cnt, flags, &xd));
+    SBTV_TRY(stage_out_buf(ctx, "op.out", out, cnt, flags, &outd));
+    double *taps_d = nullptr, *mu_d = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "op.taps", (size_t)batch * taille * taille, &taps_d));
+    SBTV_HIP(ctx, hipMemcpyAsync(taps_d, taps, sizeof(double) * batch * taille * taille, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    if (mu) {
+        SBTV_TRY(ws_get_t(ctx, "op.mu", (size_t)batch, &mu_d));
+        SBTV_HIP(ctx, hipMemcpyAsync(mu_d, mu, sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
+    }
+    double2 *Hs = nullptr, *S = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "op.H", (size_t)batch * (pl.n1 + 1) * N, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "op.S", cnt / 2, &S));
+    SBTV_TRY(psf_spectrum(ctx, pl, taps_d, taille, Hs));
+    SBTV_TRY(fft_cols_fwd(ctx, pl, xd, nullptr, S));
+    RowsArgs a{};
+    a.dir_fwd = 1;
+    a.dir_inv = 1;
+    a.op = op;
+    a.H = Hs;
+    a.mu = mu_d;
+    SBTV_TRY(fft_rows(ctx, pl, S, S, a));
+    SBTV_TRY(fft_cols_inv(ctx, pl, S, outd, 1.0 / ((double)pl.n1 * N)));
+    ctx->calls += batch;
+    SBTV_TRY(stage_out_copy(ctx, out, outd, cnt, flags));
+    if (!(flags & SBTV_DEVICE_PTRS)) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

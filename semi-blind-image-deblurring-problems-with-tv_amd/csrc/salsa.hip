@@ -1,0 +1,332 @@
+// Device-resident MAP solvers: SALSA_v2 (ADMM, SALSA/SALSA_v2.m:389-494) and
+// FISTA (SALSA/my_fista.m:5-56, my_deblur_fista.m:5-68) over the TV prox and
+// the spectral blur operator.  The host only sees a handful of scalars per
+// outer iteration (objective terms, mse, distance) and applies the stopping
+// rule; images never leave HBM.
+//
+// One SALSA outer iteration (fused form):
+//   u      = prox_{(tau/mu) TV}(x - bu)   warm-started duals       (:429)
+//   S      = rfft2(u + bu)                                        (:434, FFT of mu*(u+bu) up to the factor)
+//   Xh     = (conj(H) Yh + mu S) / (|H|^2 + mu)                   (:434-436; ATy enters as conj(H) Yh)
+//   resid2 = sum |Yh - H Xh|^2 / (M N)          (Parseval for  :442-444, no second FFT pair)
+//   x      = irfft2(Xh)
+//   bu    += u - x ; g = x - bu ; sums for mse / distance           (:440,446-451)
+#include <chrono>
+#include <cmath>
+
+#include "sbtv_internal.h"
+
+namespace sbtv {
+
+struct Collect {
+    // partial-sum sources of one outer iteration
+    const double *acc;      // rows kernel: [batch][3][nrb]
+    int nrb;
+    const double *tvp;      // tvnorm partials [batch][ntv]
+    int ntv;
+    const double *post;     // post kernel partials [batch][5][npb]
+    int npb;
+};
+
+// one block per image: assemble SalsaScal from the partial arrays (fixed order)
+__global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, const ProxCtrl *__restrict__ ctrl,
+                                                             SalsaScal *__restrict__ out) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    auto block_sum = [&](const double *p, int n) -> double {
+        double s = 0.0;
+        if (p)
+            for (int q = threadIdx.x; q < n; q += 256) s += p[q];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const double resid2 = block_sum(c.acc ? c.acc + ((size_t)b * 3) * c.nrb : nullptr, c.nrb);
+    const double tv = block_sum(c.tvp ? c.tvp + (size_t)b * c.ntv : nullptr, c.ntv);
+    double ps[5];
+    for (int q = 0; q < 5; ++q) ps[q] = block_sum(c.post ? c.post + ((size_t)b * 5 + q) * c.npb : nullptr, c.npb);
+    if (threadIdx.x == 0) {
+        SalsaScal s;
+        s.resid2 = resid2;
+        s.tv_u = tv;
+        s.mse_num = ps[0];
+        s.dist_num = ps[1];
+        s.x2 = ps[2];
+        s.u2 = ps[3];
+        s.dx2 = ps[4];
+        s.pad = ctrl ? (double)ctrl[b].k : 0.0;   // Chambolle iterations actually run
+        out[b] = s;
+    }
+}
+
+
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+void sbtv_salsa_opts_default(sbtv_salsa_opts *o) {
+    if (!o) return;
+    o->stopcriterion = 1;      // SALSA_v2.m:171
+    o->maxiter = 10000;        // :173
+    o->TViters = 5;            // :181
+    o->initialization = 0;     // :174
+    o->compute_mse = 0;        // :172
+    o->speculate = 0;
+    o->tolA = 0.001;           // :178
+    o->chambolle_tol = 1e-3;   // chambolle_prox_TV_stop.m:78
+    o->chambolle_tau = 0.249;  // chambolle_prox_TV_stop.m:77
+}
+
+int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const double *taps, int taille,
+                  const double *tau, const double *mu, const sbtv_salsa_opts *opts, const double *true_x,
+                  const double *x_init, double *x_out, double *objective, double *distance, double *times,
+                  double *mses, int *numA, int *numAt, int *n_outer, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    if (!y || !tau || !mu || !opts || batch < 1) return fail(ctx, SBTV_ERR_BADARG, "SALSA_v2: missing required argument");
+    if (!taps) return fail(ctx, SBTV_ERR_MISSING_AT, "The function handle for transpose of A is missing");
+    if (opts->stopcriterion < 1 || opts->stopcriterion > 3) return fail(ctx, SBTV_ERR_STOPCRITERION, "Unknown stopping criterion");
+    if (opts->initialization != 0 && opts->initialization != 2 && opts->initialization != 33333)
+        return fail(ctx, SBTV_ERR_INIT, "Unknown 'Initialization' option");
+    if (opts->initialization == 33333 && !x_init) return fail(ctx, SBTV_ERR_INIT, "Initialization = array but x_init is NULL");
+    if (opts->TViters <= 0) return fail(ctx, SBTV_ERR_MAXITER, "SALSA_v2: TViters must be positive");
+    if (taille < 1 || taille > 15 || taille > M || taille > N) return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
+    for (int b = 0; b < batch; ++b)
+        if (!(mu[b] > 0.0)) return fail(ctx, SBTV_ERR_MISSING_LS, "(A^T A + mu I)^(-1) must be specified: mu must be > 0");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    FftPlan fp;
+    SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
+    ProxPlan pp;
+    SBTV_TRY(prox_plan(ctx, M, N, batch, &pp));
+    const size_t P = (size_t)M * N, cnt = P * batch;
+    const int maxiter = opts->maxiter;
+    const bool want_mse = (true_x != nullptr);
+    const bool crit2 = (opts->stopcriterion == 2);
+
+    // ---- stage inputs
+    const double *yd = nullptr, *td = nullptr, *xi = nullptr;
+    SBTV_TRY(stage_in(ctx, "salsa.y", y, cnt, flags, &yd));
+    SBTV_TRY(stage_in(ctx, "salsa.true", true_x, cnt, flags, &td));
+    SBTV_TRY(stage_in(ctx, "salsa.xinit", x_init, cnt, flags, &xi));
+    double *x = nullptr, *xn = nullptr, *u = nullptr, *bu = nullptr, *g = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.x", cnt, &x));
+    SBTV_TRY(ws_get_t(ctx, "salsa.u", cnt, &u));
+    SBTV_TRY(ws_get_t(ctx, "salsa.bu", cnt, &bu));
+    SBTV_TRY(ws_get_t(ctx, "salsa.g", cnt, &g));
+    if (crit2) SBTV_TRY(ws_get_t(ctx, "salsa.xn", cnt, &xn));
+    double2 *S = nullptr, *Hs = nullptr, *Ys = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.S", cnt / 2, &S));
+    SBTV_TRY(ws_get_t(ctx, "salsa.H", (size_t)batch * (fp.n1 + 1) * N, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "salsa.Y", (size_t)batch * (fp.n1 + 1) * N, &Ys));
+    // small per-image parameter arrays: [taps | mu | thr]
+    double *par = nullptr;
+    const size_t npar = (size_t)batch * taille * taille + 2 * (size_t)batch;
+    SBTV_TRY(ws_get_t(ctx, "salsa.par", npar, &par));
+    double *taps_d = par, *mu_d = par + (size_t)batch * taille * taille, *thr_d = mu_d + batch;
+    {
+        std::vector<double> h(npar);
+        for (size_t q = 0; q < (size_t)batch * taille * taille; ++q) h[q] = taps[q];
+        for (int b = 0; b < batch; ++b) {
+            h[(size_t)batch * taille * taille + b] = mu[b];
+            h[(size_t)batch * taille * taille + batch + b] = tau[b] / mu[b];   // threshold = tau/mu (:394)
+        }
+        SBTV_HIP(ctx, hipMemcpyAsync(par, h.data(), sizeof(double) * npar, hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    }
+    int *frozen_d = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.frozen", (size_t)batch, &frozen_d));
+    SBTV_HIP(ctx, hipMemsetAsync(frozen_d, 0, sizeof(int) * batch, ctx->stream));
+    const int nrb = fft_rows_blocks(fp);
+    const int npb = ew_blocks(P);
+    double *acc = nullptr, *postp = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.acc", (size_t)batch * 3 * nrb, &acc));
+    SBTV_TRY(ws_get_t(ctx, "salsa.post", (size_t)batch * 5 * npb, &postp));
+    SalsaScal *scal_d = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.scal", (size_t)batch, &scal_d));
+    SalsaScal *scal_h = nullptr;
+    {
+        void *pz = nullptr;
+        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * batch, &pz));
+        scal_h = static_cast<SalsaScal *>(pz);
+    }
+    const double inv_scale = 1.0 / ((double)fp.n1 * N);
+    const double parseval = 1.0 / ((double)M * N);
+
+    // ---- operator spectra: H from the taps (resize.m), Yh = fft2(y)
+    SBTV_TRY(psf_spectrum(ctx, fp, taps_d, taille, Hs));
+    {
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.op = OP_NONE;
+        SBTV_TRY(fft_cols_fwd(ctx, fp, yd, nullptr, S));
+        SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+        SBTV_TRY(spec_unpack(ctx, fp, S, Ys));
+    }
+    std::vector<int> h_numA(batch, 0), h_numAt(batch, 1);   // ATy = AT(y) (:288-289)
+    ctx->calls += 2LL * batch;                               // AT(y), invLS(ATy) size check (:298)
+
+    // ---- initialisation (:366-381)
+    if (opts->initialization == 0) {
+        SBTV_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * cnt, ctx->stream));   // AT(zeros) == 0
+        ctx->calls += batch;
+    } else if (opts->initialization == 2) {
+        // x = ATy = real(ifft2(conj(H) .* fft2(y)))
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.dir_inv = 1;
+        a.op = OP_MUL_HC;
+        a.H = Hs;
+        SBTV_TRY(fft_cols_fwd(ctx, fp, yd, nullptr, S));
+        SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+        SBTV_TRY(fft_cols_inv(ctx, fp, S, x, inv_scale));
+    } else {
+        SBTV_HIP(ctx, hipMemcpyAsync(x, xi, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // u = x ; bu = 0 ; g = x - bu = x (:392-393) ; duals zero (:418-421)
+    SBTV_HIP(ctx, hipMemcpyAsync(u, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipMemcpyAsync(g, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipMemsetAsync(bu, 0, sizeof(double) * cnt, ctx->stream));
+    SBTV_TRY(prox_zero_duals(ctx, pp));
+    SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
+
+    // ---- initial objective (:399-401): resid = y - A(x)
+    double *tvp = nullptr;
+    int ntv = 0;
+    {
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.op = OP_RESID;
+        a.H = Hs;
+        a.Y = Ys;
+        a.acc = acc;
+        SBTV_TRY(fft_cols_fwd(ctx, fp, x, nullptr, S));
+        SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
+        SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));
+        double *o4 = nullptr;
+        SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
+        if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
+        Collect c{acc, nrb, tvp, ntv, nullptr, 0};
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)nullptr, scal_d);
+        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<double> h4((size_t)batch * 4, 0.0);
+        if (want_mse) SBTV_HIP(ctx, hipMemcpyAsync(h4.data(), o4, sizeof(double) * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < batch; ++b) {
+            h_numA[b] += 1;
+            const double f0 = 0.5 * (scal_h[b].resid2 * parseval) + tau[b] * scal_h[b].tv_u;
+            if (objective) objective[(size_t)b * (maxiter + 1)] = f0;
+            if (times) times[(size_t)b * (maxiter + 1)] = 0.0;
+            if (mses && want_mse) mses[(size_t)b * (maxiter + 1)] = h4[(size_t)b * 4] / (double)P;
+        }
+        ctx->calls += batch;
+    }
+    std::vector<double> obj_prev(batch), obj_cur(batch);
+    for (int b = 0; b < batch; ++b) obj_prev[b] = 0.5 * (scal_h[b].resid2 * parseval) + tau[b] * scal_h[b].tv_u;
+
+    std::vector<int> frozen(batch, 0), h_nouter(batch, 0);
+    int active = batch;
+    double ms_prox = 0.0;
+    long long prox_launches = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+
+    for (int outer = 1; outer <= maxiter && active > 0; ++outer) {
+        // (1) TV prox with warm-started duals (:429)
+        if (outer > 1) SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, frozen_d));
+        SBTV_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters));
+        SBTV_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        SBTV_TRY(prox_finish(ctx, pp, g, u));
+        SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));
+        // (2) LS step in the spectral domain + residual energy (:434-444)
+        {
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.dir_inv = 1;
+            a.op = OP_SALSA;
+            a.H = Hs;
+            a.Y = Ys;
+            a.mu = mu_d;
+            a.acc = acc;
+            a.frozen = frozen_d;
+            SBTV_TRY(fft_cols_fwd_f(ctx, fp, u, bu, S, frozen_d));
+            SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+            SBTV_TRY(fft_cols_inv_f(ctx, fp, S, crit2 ? xn : x, inv_scale, frozen_d));
+        }
+        // (3) bu update, next prox input, sums (:440-451)
+        SBTV_TRY(salsa_post(ctx, crit2 ? xn : x, x, u, bu, g, td, postp, P, batch, frozen_d, crit2 ? 1 : 0));
+        {
+            Collect c{acc, nrb, tvp, ntv, postp, npb};
+            hipLaunchKernelGGL(salsa_collect_kernel, dim3(batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)pp.ctrl, scal_d);
+        }
+        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            float ms = 0.f;
+            SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+            ms_prox += ms;
+        }
+        const double tnow = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        bool changed = false;
+        for (int b = 0; b < batch; ++b) {
+            if (frozen[b]) continue;
+            const SalsaScal &s = scal_h[b];
+            h_numA[b] += 1;
+            h_nouter[b] = outer;
+            prox_launches += (long long)s.pad;
+            ctx->calls += 2;   // invLS + A (callcounter)
+            const double f = 0.5 * (s.resid2 * parseval) + tau[b] * s.tv_u;                  // :444
+            if (objective) objective[(size_t)b * (maxiter + 1) + outer] = f;
+            if (mses && want_mse) mses[(size_t)b * (maxiter + 1) + outer] = s.mse_num / (double)P;   // :446-449
+            if (distance) distance[(size_t)b * maxiter + (outer - 1)] = sqrt(s.dist_num) / sqrt(s.x2 + s.u2);   // :451
+            if (times) times[(size_t)b * (maxiter + 1) + outer] = tnow;
+            bool stop = false;
+            if (outer > 1) {                                                                  // :453
+                double crit;
+                if (opts->stopcriterion == 1)
+                    crit = fabs(f - obj_prev[b]) / obj_prev[b];                               // :458
+                else if (opts->stopcriterion == 2)
+                    crit = fabs(sqrt(s.dx2) / sqrt(s.x2));                                    // :462
+                else
+                    crit = f;                                                                 // :465
+                stop = crit < opts->tolA;                                                     // :472
+            }
+            obj_prev[b] = f;
+            if (stop) {
+                frozen[b] = 1;
+                --active;
+                changed = true;
+            }
+        }
+        if (changed && active > 0)
+            SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen.data(), sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f;
+        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->timing[0] = ms;
+        ctx->timing[1] = ms_prox;
+        ctx->timing[2] = (double)prox_launches / batch;      // image-iterations averaged over the batch
+        ctx->timing[3] = 40.0 * (double)P * (double)prox_launches;
+    }
+    if (x_out) {
+        if (flags & SBTV_DEVICE_PTRS)
+            SBTV_HIP(ctx, hipMemcpyAsync(x_out, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            SBTV_HIP(ctx, hipMemcpyAsync(x_out, x, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (int b = 0; b < batch; ++b) {
+        if (numA) numA[b] = h_numA[b];
+        if (numAt) numAt[b] = h_numAt[b];
+        if (n_outer) n_outer[b] = h_nouter[b];
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// Internal declarations shared by the libsbtv.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sbtv.h"
+
+namespace sbtv {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+// ---------------------------------------------------------------------------
+// per-image control block of one TV prox (device resident)
+// ---------------------------------------------------------------------------
+struct ProxCtrl {
+    int k;         // iterations run so far
+    int done;      // 1: stop rule met -> iteration kernels return at once
+    int cur;       // which dual ping-pong buffer holds the current (px,py)
+    int maxiter;
+    double err;    // last err (chambolle_prox_TV_stop.m:128)
+    double lambda;
+    double tol;
+    double tau;
+};
+
+// Scalars one SALSA outer iteration hands back to the host (per image).
+struct SalsaScal {
+    double resid2;   // ||y - A x||^2 (Parseval)
+    double tv_u;     // TVnorm(u)
+    double mse_num;  // sum (x-true)^2
+    double dist_num; // sum (x-u)^2
+    double x2;       // sum x^2
+    double u2;       // sum u^2
+    double dx2;      // sum (x-xprev)^2  (criterion 2)
+    double pad;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace sbtv
+
+struct sbtv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    long long calls = 0;
+    double timing[4] = {0, 0, 0, 0};
+    std::map<std::string, sbtv::DevBuf> ws;   // named device workspaces (grow-only)
+    std::map<int, double2 *> twiddles;         // n -> exp(-2 pi i k / n), k < n
+    void *pinned = nullptr;                    // pinned host staging for scalar read-back
+    size_t pinned_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int cu_count = 256;
+};
+
+namespace sbtv {
+
+int fail(sbtv_ctx *ctx, int code, const std::string &msg);
+int fail_hip(sbtv_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
+void set_global_error(const std::string &msg);
+
+#define SBTV_HIP(ctx, expr)                                                     \
+    do {                                                                        \
+        hipError_t e__ = (expr);                                                \
+        if (e__ != hipSuccess) return sbtv::fail_hip((ctx), e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define SBTV_TRY(expr)             \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// grow-only named workspace on the context's device
+int ws_get(sbtv_ctx *ctx, const char *name, size_t bytes, void **out);
+template <typename T>
+inline int ws_get_t(sbtv_ctx *ctx, const char *name, size_t count, T **out) {
+    void *p = nullptr;
+    int rc = ws_get(ctx, name, count * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+int pinned_get(sbtv_ctx *ctx, size_t bytes, void **out);
+int twiddle_get(sbtv_ctx *ctx, int n, const double2 **out);
+
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// Stage an image argument: returns a device pointer for `p` (copying from the
+// host into workspace `name` when the caller passed host pointers).
+int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int flags, const double **dev);
+// Output staging: device pointer to write into; stage_out copies back if host.
+int stage_out_buf(sbtv_ctx *ctx, const char *name, double *p, size_t count, int flags, double **dev);
+int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count, int flags);
+
+// ----------------------------- TV kernels (tv.hip) --------------------------
+struct ProxPlan {
+    int M, N, batch;
+    int tiles_i, tiles_j, nblk;   // blocks per image
+    ProxCtrl *ctrl;               // [batch]
+    double *pbuf;                 // [2 pingpong][2 (px,py)][batch][M*N]
+    double *partials;             // [batch][nblk]
+};
+int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan);
+// (Re)initialise the control blocks: k=0, done=0 and the per-image lambda from a
+// DEVICE array `lambda_dev` scaled by `lambda_scale`; keep_cur keeps the
+// ping-pong index (warm start from the duals of the previous call).
+int prox_reset(sbtv_ctx *ctx, const ProxPlan &pl, const double *lambda_dev, double lambda_scale,
+               int maxiter, double tol, double tau, bool keep_cur, const int *frozen);
+int prox_zero_duals(sbtv_ctx *ctx, const ProxPlan &pl);
+int prox_set_duals(sbtv_ctx *ctx, const ProxPlan &pl, const double *px, const double *py);   // device ptrs
+int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);               // device ptrs
+// Run up to `maxiter` iterations (device-side early exit), no host sync.
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter);
+// f = g - lambda * div(p)
+int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
+// periodic TV norm of x -> out_dev[batch] (device)
+int tvnorm_dev(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double *out_dev);
+// same without the final reduction: per-block partials [batch][nblk] (workspace owned)
+int tvnorm_partials(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double **partials, int *nblk);
+
+// ----------------------------- FFT / operator (fft.hip) ---------------------
+enum SpecOp {
+    OP_NONE = 0,      // plain transform
+    OP_MUL_H = 1,     // X *= H
+    OP_MUL_HC = 2,    // X *= conj(H)
+    OP_INVLS = 3,     // X /= (|H|^2 + mu)
+    OP_SALSA = 4,     // X = (conj(H) Y + mu S) / (|H|^2+mu);  acc += w |Y - H X|^2
+    OP_RESID = 5,     // acc += w |H X - Y|^2 (no write)
+    OP_GRAD = 6,      // X = conj(H) (H X - Y) ; acc0 += w|HX-Y|^2 ; acc1/2 += w Re(D1/2 X conj(HX-Y))
+    OP_ATA = 7,       // X *= |H|^2
+    OP_GRADF = 8,     // X = conj(H) (H X - Y) ; acc0 += w|HX-Y|^2
+};
+struct FftPlan {
+    int M, N, batch;
+    int n1;                 // M/2  (column transform length, complex)
+    const double2 *tw_n1;   // twiddles of length n1
+    const double2 *tw_M;    // twiddles of length M (split step)
+    const double2 *tw_N;    // twiddles of length N
+};
+int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *plan);
+// real M x N (x batch) -> packed half spectrum S (M/2 x N complex), column pass only + row pass
+// `add` (optional) is added to `x` on load (x + add).
+int fft_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S);
+int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale);
+struct RowsArgs {
+    int dir_fwd;            // 1: apply forward row FFT first
+    int dir_inv;            // 1: apply inverse row FFT last
+    int op;                 // SpecOp
+    const double2 *H;       // (M/2+1) x N per image (unpacked rows 0..M/2)
+    const double2 *Y;       // same layout (OP_SALSA / OP_RESID / OP_GRAD)
+    const double2 *D1, *D2; // derivative spectra (OP_GRAD), may be null
+    const double *mu;       // per image (device)
+    double *acc;            // partial sums [batch][3][nblk_rows]
+    const int *frozen;      // optional per-image flag: skip image when set
+};
+int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout, const RowsArgs &a);
+int fft_rows_blocks(const FftPlan &pl);   // number of row blocks per image (acc stride)
+// unpack packed spectrum S -> full rows 0..M/2 layout ((M/2+1) x N)
+int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U);
+// direct evaluation of the tap spectrum: U[(M/2+1) x N] per image from taps[batch][taille^2] (device)
+int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U);
+
+// ----------------------------- elementwise (elementwise.hip) ----------------
+// generic deterministic final reduction: out[b*nout + q] = sum_i partials[(b*nout+q)*n + i]
+int reduce_partials(sbtv_ctx *ctx, const double *partials, int nvec, int n, double *out);
+int ew_blocks(size_t P);
+int salsa_post(sbtv_ctx *ctx, const double *xn, double *x, const double *u, double *bu, double *g, const double *tru,
+               double *partials, size_t P, int batch, const int *frozen, int copy_x);
+// out4_dev[b*4 + {0,1,2,3}] = sum (a-c)^2, sum a^2, sum c^2, max a
+int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev);
+int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot);
+int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, const double *coef_dev,
+                   double *partials, size_t P, int batch, const int *frozen);
+int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
+               const double *sigma2_dev, double gam, double lamb, size_t P, int batch);
+int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S, const int *frozen);
+int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen);
+
+}  // namespace sbtv

@@ -1,0 +1,517 @@
+// TV primitives on gfx950: the Chambolle dual-projection iteration (K1), the
+// final f = g - lambda div p (K2) and the periodic isotropic TV norm (K3).
+//
+// Arithmetic follows utils/chambolle_prox_TV_stop.m:120-166 of the reference
+// operation for operation (fp contraction is disabled in this file so a
+// multiply-add sequence rounds exactly like MATLAB's separate operations).
+//
+// Data layout: column-major, i (row) is the contiguous axis.  One workgroup of
+// 256 threads (4 wave64) owns a tile of TI=128 rows x TJ=16 columns; lane l of
+// a wave owns the row pair (2l, 2l+1) so global accesses are 16-byte (double2)
+// per lane and fully coalesced.  u = div p - g/lambda is computed once per
+// pixel (plus a one-row / one-column halo) into LDS, then the forward
+// differences of u are read back from LDS.
+#include "sbtv_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace sbtv {
+
+constexpr int TI = 128;          // tile rows   (64 lanes x 2 rows)
+constexpr int TJ = 16;           // tile columns (4 waves x 4 columns)
+constexpr int CJ = TJ / 4;       // columns per wave
+constexpr int ULD = TI + 2;      // LDS leading dimension of the u tile (even -> 16 B aligned rows)
+constexpr int TVB = 256;         // threads per block
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// deterministic block sum for 256 threads; result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double *red /*[4]*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (red[0] + red[1]) + (red[2] + red[3]);
+    return r;
+}
+
+// x-divergence term at row i (chambolle_prox_TV_stop.m:156-157):
+//   i == 0: p(0) ; 0 < i < M-1: p(i) - p(i-1) ; i == M-1: -p(M-1)
+__device__ __forceinline__ double div1(double p, double pm, int i, int n) {
+    return (i == 0) ? p : ((i == n - 1) ? -p : (p - pm));
+}
+
+template <bool VEC>
+__device__ __forceinline__ double2 ld2(const double *__restrict__ base, size_t off, bool ok0, bool ok1) {
+    double2 r = make_double2(0.0, 0.0);
+    if (VEC) {
+        if (ok1) {
+            r = *reinterpret_cast<const double2 *>(base + off);
+        } else if (ok0) {
+            r.x = base[off];
+        }
+    } else {
+        if (ok0) r.x = base[off];
+        if (ok1) r.y = base[off + 1];
+    }
+    return r;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void st2(double *__restrict__ base, size_t off, double2 v, bool ok0, bool ok1) {
+    if (VEC) {
+        if (ok1) {
+            *reinterpret_cast<double2 *>(base + off) = v;
+        } else if (ok0) {
+            base[off] = v.x;
+        }
+    } else {
+        if (ok0) base[off] = v.x;
+        if (ok1) base[off + 1] = v.y;
+    }
+}
+
+// One Chambolle iteration (chambolle_prox_TV_stop.m:121-130) on every image of
+// the batch whose control block is not `done`.
+template <bool VEC>
+__global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__restrict__ g, double *__restrict__ pbuf,
+                                                              const ProxCtrl *__restrict__ ctrl,
+                                                              double *__restrict__ partials, int M, int N,
+                                                              int batch, int tiles_i) {
+    const int b = blockIdx.z;
+    const ProxCtrl c = ctrl[b];
+    if (c.done) return;
+    const size_t P = (size_t)M * N;
+    const size_t plane = P * batch;
+    const double *__restrict__ pxi = pbuf + (size_t)(c.cur * 2 + 0) * plane + (size_t)b * P;
+    const double *__restrict__ pyi = pbuf + (size_t)(c.cur * 2 + 1) * plane + (size_t)b * P;
+    double *__restrict__ pxo = pbuf + (size_t)((c.cur ^ 1) * 2 + 0) * plane + (size_t)b * P;
+    double *__restrict__ pyo = pbuf + (size_t)((c.cur ^ 1) * 2 + 1) * plane + (size_t)b * P;
+    const double *__restrict__ gg = g + (size_t)b * P;
+    const double lambda = c.lambda, tau = c.tau;
+
+    __shared__ __attribute__((aligned(16))) double u_lds[(TJ + 1) * ULD];
+    __shared__ double red[4];
+
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    const int i0 = ti * TI, j0 = tj * TJ;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int il = 2 * lane;            // local row of the pair
+    const int i = i0 + il;
+    const bool ok0 = i < M, ok1 = i + 1 < M;
+
+    double2 px[CJ], py[CJ];
+
+    // ---- phase 1: u = div p - g/lambda on the tile, its halo column and halo row
+    // halo column jl = TJ is handled by wave 0 as a fifth column
+    const int ncol = CJ + ((w == 0) ? 1 : 0);
+    double2 pym = make_double2(0.0, 0.0);       // py(i, j-1)
+    for (int c4 = 0; c4 < ncol; ++c4) {
+        const int jl = (c4 < CJ) ? (w * CJ + c4) : TJ;
+        const int j = j0 + jl;
+        if (j >= N) break;                       // wave-uniform
+        const size_t off = (size_t)j * M + i;
+        const double2 pxv = ld2<VEC>(pxi, off, ok0, ok1);
+        const double2 pyv = ld2<VEC>(pyi, off, ok0, ok1);
+        const double2 gv = ld2<VEC>(gg, off, ok0, ok1);
+        if (c4 == 0 || c4 == CJ) {
+            pym = (j > 0) ? ld2<VEC>(pyi, off - M, ok0, ok1) : make_double2(0.0, 0.0);
+        }
+        // px(i-1, j): odd row of the previous lane, or a scalar load at the tile edge
+        double pxm = __shfl_up(pxv.y, 1, 64);
+        if (lane == 0) pxm = (i > 0 && ok0) ? pxi[off - 1] : 0.0;
+        const double dx0 = div1(pxv.x, pxm, i, M);
+        const double dx1 = div1(pxv.y, pxv.x, i + 1, M);
+        const double dy0 = div1(pyv.x, pym.x, j, N);
+        const double dy1 = div1(pyv.y, pym.y, j, N);
+        double2 u;
+        u.x = (dy0 + dx0) - gv.x / lambda;       // divp = v + u (:159), u = divp - g/lambda (:124)
+        u.y = (dy1 + dx1) - gv.y / lambda;
+        *reinterpret_cast<double2 *>(&u_lds[jl * ULD + il]) = u;
+        if (c4 < CJ) {
+            px[c4] = pxv;
+            py[c4] = pyv;
+        }
+        pym = pyv;
+    }
+    // halo row il = TI (global row i0+TI) for the TJ columns: wave 1, lanes 0..TJ-1
+    if (w == 1 && lane < TJ) {
+        const int ih = i0 + TI;
+        const int j = j0 + lane;
+        if (ih < M && j < N) {
+            const size_t off = (size_t)j * M + ih;
+            const double pxv = pxi[off], pxm = pxi[off - 1];
+            const double pyv = pyi[off];
+            const double pymv = (j > 0) ? pyi[off - M] : 0.0;
+            const double dx = div1(pxv, pxm, ih, M);
+            const double dy = div1(pyv, pymv, j, N);
+            u_lds[lane * ULD + TI] = (dy + dx) - gg[off] / lambda;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: gradient of u, error term with the OLD p, dual update
+    double esum = 0.0;
+#pragma unroll
+    for (int c4 = 0; c4 < CJ; ++c4) {
+        const int jl = w * CJ + c4;
+        const int j = j0 + jl;
+        if (j < N) {
+            const double2 uc = *reinterpret_cast<const double2 *>(&u_lds[jl * ULD + il]);
+            const double ud = u_lds[jl * ULD + il + 2];                 // u(i+2, j)
+            const double2 ur = *reinterpret_cast<const double2 *>(&u_lds[(jl + 1) * ULD + il]);
+            const bool jin = (j < N - 1);
+            // GradientIm (:161-166): last row of dux and last column of duy are zero
+            const double upx0 = (i < M - 1) ? (uc.y - uc.x) : 0.0;
+            const double upx1 = (i + 1 < M - 1) ? (ud - uc.y) : 0.0;
+            const double upy0 = jin ? (ur.x - uc.x) : 0.0;
+            const double upy1 = jin ? (ur.y - uc.y) : 0.0;
+            const double t0 = sqrt(upx0 * upx0 + upy0 * upy0);          // :127
+            const double t1 = sqrt(upx1 * upx1 + upy1 * upy1);
+            if (ok0) {
+                const double a = -upx0 + t0 * px[c4].x, bb = -upy0 + t0 * py[c4].x;   // :128
+                esum += a * a + bb * bb;
+            }
+            if (ok1) {
+                const double a = -upx1 + t1 * px[c4].y, bb = -upy1 + t1 * py[c4].y;
+                esum += a * a + bb * bb;
+            }
+            double2 npx, npy;
+            npx.x = (px[c4].x + tau * upx0) / (1.0 + tau * t0);         // :129
+            npx.y = (px[c4].y + tau * upx1) / (1.0 + tau * t1);
+            npy.x = (py[c4].x + tau * upy0) / (1.0 + tau * t0);         // :130
+            npy.y = (py[c4].y + tau * upy1) / (1.0 + tau * t1);
+            const size_t off = (size_t)j * M + i;
+            st2<VEC>(pxo, off, npx, ok0, ok1);
+            st2<VEC>(pyo, off, npy, ok0, ok1);
+        }
+    }
+    const double bs = block_sum_256(esum, red);
+    if (threadIdx.x == 0) partials[(size_t)b * (gridDim.x * gridDim.y) + (size_t)tj * tiles_i + ti] = bs;
+}
+
+// Sum the per-block partials in a fixed order, then apply the stop rule
+// cont = (k < MaxIter) & (err > tol)   (chambolle_prox_TV_stop.m:131)
+__global__ __launch_bounds__(256) void chambolle_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
+                                                              const double *__restrict__ partials, int nblk) {
+    const int b = blockIdx.x;
+    ProxCtrl *c = &ctrl[b];
+    if (c->done) return;
+    __shared__ double red[4];
+    const double *p = partials + (size_t)b * nblk;
+    double s = 0.0;
+    for (int q = threadIdx.x; q < nblk; q += 256) s += p[q];
+    const double tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+        const int k = c->k + 1;
+        const double err = sqrt(tot);
+        c->k = k;
+        c->err = err;
+        c->cur ^= 1;
+        c->done = !((k < c->maxiter) && (err > c->tol));
+    }
+}
+
+__global__ void prox_reset_kernel(ProxCtrl *__restrict__ ctrl, const double *__restrict__ lambda,
+                                  double lambda_scale, int maxiter, double tol, double tau, int keep_cur,
+                                  int batch, const int *__restrict__ frozen) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    ProxCtrl c = ctrl[b];
+    c.k = 0;
+    c.done = (frozen && frozen[b]) ? 1 : 0;
+    if (!keep_cur) c.cur = 0;
+    c.maxiter = maxiter;
+    c.err = 0.0;
+    c.lambda = lambda[b] * lambda_scale;
+    c.tol = tol;
+    c.tau = tau;
+    ctrl[b] = c;
+}
+
+// f = g - lambda * DivergenceIm(px, py)   (chambolle_prox_TV_stop.m:149)
+template <bool VEC>
+__global__ __launch_bounds__(TVB) void chambolle_finish_kernel(const double *__restrict__ g,
+                                                                const double *__restrict__ pbuf,
+                                                                const ProxCtrl *__restrict__ ctrl,
+                                                                double *__restrict__ f, int M, int N, int batch) {
+    const int b = blockIdx.z;
+    const ProxCtrl c = ctrl[b];
+    const size_t P = (size_t)M * N;
+    const size_t plane = P * batch;
+    const double *__restrict__ px = pbuf + (size_t)(c.cur * 2 + 0) * plane + (size_t)b * P;
+    const double *__restrict__ py = pbuf + (size_t)(c.cur * 2 + 1) * plane + (size_t)b * P;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * TI + 2 * lane;
+    const bool ok0 = i < M, ok1 = i + 1 < M;
+    const double lambda = c.lambda;
+#pragma unroll
+    for (int c4 = 0; c4 < CJ; ++c4) {
+        const int j = blockIdx.y * TJ + w * CJ + c4;
+        if (j >= N) break;
+        const size_t off = (size_t)j * M + i;
+        const double2 pxv = ld2<VEC>(px, off, ok0, ok1);
+        const double2 pyv = ld2<VEC>(py, off, ok0, ok1);
+        const double2 gv = ld2<VEC>(g + (size_t)b * P, off, ok0, ok1);
+        const double2 pym = (j > 0) ? ld2<VEC>(py, off - M, ok0, ok1) : make_double2(0.0, 0.0);
+        double pxm = __shfl_up(pxv.y, 1, 64);
+        if (lane == 0) pxm = (i > 0 && ok0) ? px[off - 1] : 0.0;
+        double2 r;
+        r.x = gv.x - lambda * (div1(pyv.x, pym.x, j, N) + div1(pxv.x, pxm, i, M));
+        r.y = gv.y - lambda * (div1(pyv.y, pym.y, j, N) + div1(pxv.y, pxv.x, i + 1, M));
+        st2<VEC>(f + (size_t)b * P, off, r, ok0, ok1);
+    }
+}
+
+// Periodic isotropic TV (utils/TVnorm.m:2, SALSA/diffh.m, diffv.m):
+//   sum sqrt( (x(i,j)-x(i,j-1))^2 + (x(i,j)-x(i-1,j))^2 ), indices modulo the size
+template <bool VEC>
+__global__ __launch_bounds__(TVB) void tvnorm_kernel(const double *__restrict__ x, double *__restrict__ partials,
+                                                      int M, int N, int tiles_i) {
+    const int b = blockIdx.z;
+    const size_t P = (size_t)M * N;
+    const double *__restrict__ xb = x + (size_t)b * P;
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * TI + 2 * lane;
+    const bool ok0 = i < M, ok1 = i + 1 < M;
+    double s = 0.0;
+#pragma unroll
+    for (int c4 = 0; c4 < CJ; ++c4) {
+        const int j = blockIdx.y * TJ + w * CJ + c4;
+        if (j >= N) break;
+        const size_t off = (size_t)j * M + i;
+        const int jm = (j > 0) ? j - 1 : N - 1;
+        const double2 xv = ld2<VEC>(xb, off, ok0, ok1);
+        const double2 xl = ld2<VEC>(xb, (size_t)jm * M + i, ok0, ok1);
+        double xu = __shfl_up(xv.y, 1, 64);
+        if (lane == 0 && ok0) xu = xb[(size_t)j * M + ((i > 0) ? i - 1 : M - 1)];
+        if (ok0) {
+            const double dh = xv.x - xl.x, dv = xv.x - xu;
+            s += sqrt(dh * dh + dv * dv);
+        }
+        if (ok1) {
+            const double dh = xv.y - xl.y, dv = xv.y - xv.x;
+            s += sqrt(dh * dh + dv * dv);
+        }
+    }
+    const double bs = block_sum_256(s, red);
+    if (threadIdx.x == 0) partials[(size_t)b * (gridDim.x * gridDim.y) + (size_t)blockIdx.y * tiles_i + blockIdx.x] = bs;
+}
+
+// out[v] = sum_q partials[v*n + q], fixed order
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int n,
+                                                               double *__restrict__ out) {
+    __shared__ double red[4];
+    const double *p = partials + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (int q = threadIdx.x; q < n; q += 256) s += p[q];
+    const double tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+__global__ void copy_duals_kernel(double *__restrict__ dst0, double *__restrict__ dst1,
+                                  const double *__restrict__ pbuf, const ProxCtrl *__restrict__ ctrl, size_t P,
+                                  int batch) {
+    const int b = blockIdx.y;
+    const ProxCtrl c = ctrl[b];
+    const size_t plane = P * batch;
+    const double *px = pbuf + (size_t)(c.cur * 2 + 0) * plane + (size_t)b * P;
+    const double *py = pbuf + (size_t)(c.cur * 2 + 1) * plane + (size_t)b * P;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < P; q += (size_t)gridDim.x * blockDim.x) {
+        dst0[(size_t)b * P + q] = px[q];
+        dst1[(size_t)b * P + q] = py[q];
+    }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+
+static inline bool vec_ok(const void *p, int M) { return (M % 2 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
+
+int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl) {
+    pl->M = M;
+    pl->N = N;
+    pl->batch = batch;
+    pl->tiles_i = (M + TI - 1) / TI;
+    pl->tiles_j = (N + TJ - 1) / TJ;
+    pl->nblk = pl->tiles_i * pl->tiles_j;
+    const size_t P = (size_t)M * N;
+    SBTV_TRY(ws_get_t(ctx, "prox.ctrl", (size_t)batch, &pl->ctrl));
+    SBTV_TRY(ws_get_t(ctx, "prox.pbuf", 4 * P * batch, &pl->pbuf));
+    SBTV_TRY(ws_get_t(ctx, "prox.partials", (size_t)batch * pl->nblk, &pl->partials));
+    return 0;
+}
+
+int prox_reset(sbtv_ctx *ctx, const ProxPlan &pl, const double *lambda_dev, double lambda_scale, int maxiter,
+               double tol, double tau, bool keep_cur, const int *frozen) {
+    const int thr = 64;
+    hipLaunchKernelGGL(prox_reset_kernel, dim3((pl.batch + thr - 1) / thr), dim3(thr), 0, ctx->stream, pl.ctrl,
+                       lambda_dev, lambda_scale, maxiter, tol, tau, keep_cur ? 1 : 0, pl.batch, frozen);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int prox_zero_duals(sbtv_ctx *ctx, const ProxPlan &pl) {
+    const size_t P = (size_t)pl.M * pl.N;
+    // only ping-pong slot 0 needs clearing (reset with keep_cur=false selects it)
+    SBTV_HIP(ctx, hipMemsetAsync(pl.pbuf, 0, 2 * P * pl.batch * sizeof(double), ctx->stream));
+    return 0;
+}
+
+int prox_set_duals(sbtv_ctx *ctx, const ProxPlan &pl, const double *px, const double *py) {
+    const size_t P = (size_t)pl.M * pl.N * pl.batch;
+    SBTV_HIP(ctx, hipMemcpyAsync(pl.pbuf, px, P * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipMemcpyAsync(pl.pbuf + P, py, P * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py) {
+    const size_t P = (size_t)pl.M * pl.N;
+    hipLaunchKernelGGL(copy_duals_kernel, dim3(256, pl.batch), dim3(256), 0, ctx->stream, px, py, pl.pbuf, pl.ctrl,
+                       P, pl.batch);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter) {
+    const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
+    const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
+    for (int it = 0; it < maxiter; ++it) {
+        if (v)
+            hipLaunchKernelGGL(chambolle_iter_kernel<true>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl,
+                               pl.partials, pl.M, pl.N, pl.batch, pl.tiles_i);
+        else
+            hipLaunchKernelGGL(chambolle_iter_kernel<false>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl,
+                               pl.partials, pl.M, pl.N, pl.batch, pl.tiles_i);
+        hipLaunchKernelGGL(chambolle_ctrl_kernel, dim3(pl.batch), dim3(256), 0, ctx->stream, pl.ctrl, pl.partials,
+                           pl.nblk);
+    }
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f) {
+    const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
+    const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M) && vec_ok(f, pl.M);
+    if (v)
+        hipLaunchKernelGGL(chambolle_finish_kernel<true>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl, f,
+                           pl.M, pl.N, pl.batch);
+    else
+        hipLaunchKernelGGL(chambolle_finish_kernel<false>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl, f,
+                           pl.M, pl.N, pl.batch);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int reduce_partials(sbtv_ctx *ctx, const double *partials, int nvec, int n, double *out) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nvec), dim3(256), 0, ctx->stream, partials, n, out);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int tvnorm_partials(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double **partials_out, int *nblk_out) {
+    const int tiles_i = (M + TI - 1) / TI, tiles_j = (N + TJ - 1) / TJ;
+    const int nblk = tiles_i * tiles_j;
+    double *partials = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "tv.partials", (size_t)batch * nblk, &partials));
+    const dim3 grid(tiles_i, tiles_j, batch);
+    if (vec_ok(x, M))
+        hipLaunchKernelGGL(tvnorm_kernel<true>, grid, dim3(TVB), 0, ctx->stream, x, partials, M, N, tiles_i);
+    else
+        hipLaunchKernelGGL(tvnorm_kernel<false>, grid, dim3(TVB), 0, ctx->stream, x, partials, M, N, tiles_i);
+    SBTV_HIP(ctx, hipGetLastError());
+    *partials_out = partials;
+    *nblk_out = nblk;
+    return 0;
+}
+
+int tvnorm_dev(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double *out_dev) {
+    double *partials = nullptr;
+    int nblk = 0;
+    SBTV_TRY(tvnorm_partials(ctx, x, M, N, batch, &partials, &nblk));
+    return reduce_partials(ctx, partials, batch, nblk, out_dev);
+}
+
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+int sbtv_chambolle_prox_TV_stop(sbtv_ctx *ctx, const double *g, int M, int N, int batch, const double *lambda,
+                                int maxiter, double tol, double tau, int warm_start, double *px, double *py,
+                                double *f, int *k_out, double *err_out, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    if (!g || !lambda || M < 2 || N < 2 || batch < 1)
+        return fail(ctx, SBTV_ERR_BADARG, "chambolle_prox_TV_stop: Wrong number of required parameters");
+    if (maxiter <= 0)
+        return fail(ctx, SBTV_ERR_MAXITER,
+                    "chambolle_prox_TV_stop: 'maxiter' is required (MaxIter undefined, chambolle_prox_TV_stop.m:131)");
+    if (warm_start && (!px || !py))
+        return fail(ctx, SBTV_ERR_DUALVARS, "chambolle_prox_TV_stop: Wrong size of the dual variables");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cnt = (size_t)M * N * batch;
+    ProxPlan pl;
+    SBTV_TRY(prox_plan(ctx, M, N, batch, &pl));
+    const double *gd = nullptr;
+    SBTV_TRY(stage_in(ctx, "prox.in.g", g, cnt, flags, &gd));
+    double *lam_d = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "prox.lambda", (size_t)batch, &lam_d));
+    SBTV_HIP(ctx, hipMemcpyAsync(lam_d, lambda, sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
+    SBTV_TRY(prox_reset(ctx, pl, lam_d, 1.0, maxiter, tol, tau, false, nullptr));
+    if (warm_start) {
+        const double *pxd = nullptr, *pyd = nullptr;
+        SBTV_TRY(stage_in(ctx, "prox.in.px", px, cnt, flags, &pxd));
+        SBTV_TRY(stage_in(ctx, "prox.in.py", py, cnt, flags, &pyd));
+        SBTV_TRY(prox_set_duals(ctx, pl, pxd, pyd));
+    } else {
+        SBTV_TRY(prox_zero_duals(ctx, pl));
+    }
+    SBTV_TRY(prox_iterate(ctx, pl, gd, maxiter));
+    double *fd = nullptr, *pxo = nullptr, *pyo = nullptr;
+    if (f) {
+        SBTV_TRY(stage_out_buf(ctx, "prox.out.f", f, cnt, flags, &fd));
+        SBTV_TRY(prox_finish(ctx, pl, gd, fd));
+        SBTV_TRY(stage_out_copy(ctx, f, fd, cnt, flags));
+    }
+    if (px && py) {
+        SBTV_TRY(stage_out_buf(ctx, "prox.out.px", px, cnt, flags, &pxo));
+        SBTV_TRY(stage_out_buf(ctx, "prox.out.py", py, cnt, flags, &pyo));
+        SBTV_TRY(prox_get_duals(ctx, pl, pxo, pyo));
+        SBTV_TRY(stage_out_copy(ctx, px, pxo, cnt, flags));
+        SBTV_TRY(stage_out_copy(ctx, py, pyo, cnt, flags));
+    }
+    if (k_out || err_out || !(flags & SBTV_DEVICE_PTRS)) {
+        std::vector<ProxCtrl> hc(batch);
+        SBTV_HIP(ctx, hipMemcpyAsync(hc.data(), pl.ctrl, sizeof(ProxCtrl) * batch, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < batch; ++b) {
+            if (k_out) k_out[b] = hc[b].k;
+            if (err_out) err_out[b] = hc[b].err;
+        }
+    }
+    return 0;
+}
+
+int sbtv_TVnorm(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double *out, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    if (!x || !out || M < 2 || N < 2 || batch < 1) return fail(ctx, SBTV_ERR_BADARG, "TVnorm: bad arguments");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    const double *xd = nullptr;
+    SBTV_TRY(stage_in(ctx, "tv.in.x", x, (size_t)M * N * batch, flags, &xd));
+    double *od = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "tv.out", (size_t)batch, &od));
+    SBTV_TRY(tvnorm_dev(ctx, xd, M, N, batch, od));
+    SBTV_HIP(ctx, hipMemcpyAsync(out, od, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

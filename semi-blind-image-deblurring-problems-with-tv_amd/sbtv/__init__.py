@@ -1,0 +1,19 @@
+"""sbtv — host-side mirror of the reference's operator API over libsbtv.so (MI355X / gfx950).
+
+Names follow the reference (SALSA_v2, chambolle_prox_TV_stop, TVnorm,
+A_wrapper, Gaussian_psf, ...).  Everything computes on the GPU through the
+C-ABI in include/sbtv.h; there is no CPU implementation in this package.
+"""
+from ._lib import (Context, SbtvError, default_context, load_library, to_device, to_host, LIB_PATH,
+                   SBTV_DEVICE_PTRS, SBTV_HOST_PTRS)
+from .tv import chambolle_prox_TV_stop, TVnorm
+from .operators import (BlurOperator, A_wrapper, Gaussian_psf, psf_gaussian, psf_moffat, psf_laplace, psf_family,
+                        rfft2_packed, unpack_half_spectrum)
+from .salsa import SALSA_v2
+from .metrics import PSNR, MSE
+
+__all__ = [
+    "Context", "SbtvError", "default_context", "load_library", "to_device", "to_host", "LIB_PATH",
+    "chambolle_prox_TV_stop", "TVnorm", "BlurOperator", "A_wrapper", "Gaussian_psf", "psf_gaussian",
+    "psf_moffat", "psf_laplace", "psf_family", "rfft2_packed", "unpack_half_spectrum", "SALSA_v2", "PSNR", "MSE",
+]

@@ -1,0 +1,264 @@
+"""ctypes binding of libsbtv.so (the C-ABI declared in include/sbtv.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is
+missing, or no gfx950 GPU is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsbtv.so")
+
+SBTV_HOST_PTRS = 0
+SBTV_DEVICE_PTRS = 1
+
+ERRORS = {
+    -1: "SBTV_ERR_BADARG", -2: "SBTV_ERR_SIZE", -3: "SBTV_ERR_MAXITER", -4: "SBTV_ERR_DUALVARS",
+    -5: "SBTV_ERR_MODE", -6: "SBTV_ERR_STOPCRITERION", -7: "SBTV_ERR_INIT", -8: "SBTV_ERR_MISSING_AT",
+    -9: "SBTV_ERR_MISSING_LS", -10: "SBTV_ERR_PSF", -11: "SBTV_ERR_NOMEM", -12: "SBTV_ERR_NODEVICE",
+}
+
+
+class SbtvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{ERRORS.get(code, code)}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class sbtv_salsa_opts(C.Structure):
+    _fields_ = [("stopcriterion", C.c_int), ("maxiter", C.c_int), ("TViters", C.c_int),
+                ("initialization", C.c_int), ("compute_mse", C.c_int), ("speculate", C.c_int),
+                ("tolA", C.c_double), ("chambolle_tol", C.c_double), ("chambolle_tau", C.c_double)]
+
+
+class sbtv_sapg_opts(C.Structure):
+    _fields_ = [("kind", C.c_int), ("psf_size", C.c_int), ("samples", C.c_int), ("warmup", C.c_int),
+                ("burnIn", C.c_int), ("chambolleit", C.c_int), ("fix_p", C.c_int * 2), ("fix_sigma", C.c_int),
+                ("share_gradients", C.c_int),
+                ("lambda_", C.c_double), ("gamma", C.c_double),
+                ("th_init", C.c_double), ("min_th", C.c_double), ("max_th", C.c_double),
+                ("p_init", C.c_double * 2), ("p_min", C.c_double * 2), ("p_max", C.c_double * 2),
+                ("p_true", C.c_double * 2), ("phi", C.c_double),
+                ("sigma2_init", C.c_double), ("sigma2_min", C.c_double), ("sigma2_max", C.c_double),
+                ("sigma2_true", C.c_double),
+                ("d_scale", C.c_double), ("d_exp", C.c_double),
+                ("c_theta", C.c_double), ("c_p", C.c_double * 2), ("c_sigma", C.c_double),
+                ("seed", C.c_ulonglong)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+_P = C.c_void_p
+_D = C.c_double
+_I = C.c_int
+
+# name -> (restype, argtypes); the list is also what tests check against include/sbtv.h
+SIGNATURES = {
+    "sbtv_version": (_I, []),
+    "sbtv_ctx_create": (_I, [_I, C.POINTER(_P)]),
+    "sbtv_ctx_destroy": (_I, [_P]),
+    "sbtv_last_error": (C.c_char_p, [_P]),
+    "sbtv_ctx_set_stream": (_I, [_P, _P]),
+    "sbtv_ctx_sync": (_I, [_P]),
+    "sbtv_callcounter_get": (_I, [_P, C.POINTER(C.c_longlong)]),
+    "sbtv_callcounter_reset": (_I, [_P]),
+    "sbtv_last_timing": (_I, [_P, C.POINTER(_D)]),
+    "sbtv_malloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
+    "sbtv_free": (_I, [_P, _P]),
+    "sbtv_memcpy_h2d": (_I, [_P, _P, _P, C.c_size_t]),
+    "sbtv_memcpy_d2h": (_I, [_P, _P, _P, C.c_size_t]),
+    "sbtv_chambolle_prox_TV_stop": (_I, [_P, _P, _I, _I, _I, _P, _I, _D, _D, _I, _P, _P, _P, _P, _P, _I]),
+    "sbtv_TVnorm": (_I, [_P, _P, _I, _I, _I, _P, _I]),
+    "sbtv_A_wrapper": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "sbtv_psf_taps": (_I, [_I, _I, _P, _P, _P, _P]),
+    "sbtv_rfft2_packed": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
+    "sbtv_salsa_opts_default": (None, [C.POINTER(sbtv_salsa_opts)]),
+    "sbtv_SALSA_v2": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.POINTER(sbtv_salsa_opts), _P, _P, _P, _P, _P, _P,
+                           _P, _P, _P, _P, _I]),
+    "sbtv_fista_tv": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _D, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P, _I]),
+    "sbtv_SAPG_algorithm": (_I, [_P, _P, _I, _I, _I, C.POINTER(sbtv_sapg_opts), _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 _P, _P, ALLREDUCE_FN, _P, _I]),
+    "sbtv_max_eigenval": (_I, [_P, _P, _I, _P, _I, _I, _D, _I, _P, _P, _I]),
+    "sbtv_PSNR": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
+    "sbtv_MSE": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libsbtv.so (built by `make -C csrc` / __graft_entry__.build())."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                "sbtv has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class Context:
+    """One GPU context (sbtv_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _P()
+        rc = self.lib.sbtv_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise SbtvError(rc, self.lib.sbtv_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sbtv_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise SbtvError(rc, self.lib.sbtv_last_error(self.h).decode())
+
+    def sync(self):
+        self.check(self.lib.sbtv_ctx_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.sbtv_ctx_set_stream(self.h, _P(stream_ptr)))
+
+    @property
+    def calls(self):
+        v = C.c_longlong(0)
+        self.check(self.lib.sbtv_callcounter_get(self.h, C.byref(v)))
+        return v.value
+
+    def reset_calls(self):
+        self.check(self.lib.sbtv_callcounter_reset(self.h))
+
+    def last_timing(self):
+        out = (C.c_double * 4)()
+        self.check(self.lib.sbtv_last_timing(self.h, out))
+        return dict(loop_ms=out[0], chambolle_ms=out[1], chambolle_launches=out[2], chambolle_bytes=out[3])
+
+
+_default_ctx = {}
+
+
+def default_context(device=None) -> Context:
+    if device is None:
+        device = int(os.environ.get("SBTV_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ---------------------------------------------------------------------------
+# image marshalling: MATLAB column-major doubles
+# ---------------------------------------------------------------------------
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Images:
+    """A batch of M x N images ready for the C-ABI.
+
+    numpy input: (M,N) or (B,M,N) arrays (any order/dtype) -> host pointer to a
+    (B, N, M) C-contiguous float64 copy (== column-major per image).
+    torch CUDA input: tensor whose memory already is column-major per image,
+    i.e. shape (M,N) with strides (1,M) or (B,M,N) with strides (M*N,1,M)
+    (use `to_device`) -> device pointer, no copy.
+    """
+
+    def __init__(self, x, like=None):
+        self.torch = _is_torch(x)
+        if self.torch:
+            if x.dtype is not __import__("torch").float64:
+                raise TypeError("device images must be float64")
+            if x.dim() == 2:
+                x = x.unsqueeze(0)
+            B, M, N = x.shape
+            if x.stride() != (M * N, 1, M):
+                raise ValueError("device images must be column-major per image: use sbtv.to_device()")
+            if not x.is_cuda:
+                raise ValueError("torch images must live on the GPU (numpy arrays are the host path)")
+            self.t = x
+            self.B, self.M, self.N = B, M, N
+            self.ptr = _P(x.data_ptr())
+            self.flags = SBTV_DEVICE_PTRS
+        else:
+            a = np.asarray(x, dtype=np.float64)
+            self.squeeze = (a.ndim == 2)
+            if a.ndim == 2:
+                a = a[None]
+            if a.ndim != 3:
+                raise ValueError("images must be (M,N) or (B,M,N)")
+            self.B, self.M, self.N = a.shape
+            self.buf = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))   # (B,N,M): column-major images
+            self.ptr = self.buf.ctypes.data_as(_P)
+            self.flags = SBTV_HOST_PTRS
+
+
+def empty_like_images(ref: Images):
+    """Output buffer matching `ref` (host numpy or device torch)."""
+    if ref.torch:
+        import torch
+        t = torch.empty((ref.B, ref.N, ref.M), dtype=torch.float64, device=ref.t.device).permute(0, 2, 1)
+        return Images(t)
+    out = Images.__new__(Images)
+    out.torch = False
+    out.squeeze = getattr(ref, "squeeze", False)
+    out.B, out.M, out.N = ref.B, ref.M, ref.N
+    out.buf = np.empty((ref.B, ref.N, ref.M), dtype=np.float64)
+    out.ptr = out.buf.ctypes.data_as(_P)
+    out.flags = SBTV_HOST_PTRS
+    return out
+
+
+def images_result(img: Images, squeeze=None):
+    """Back to the caller's convention: numpy (M,N)/(B,M,N) or the torch tensor."""
+    if img.torch:
+        return img.t[0] if squeeze else img.t
+    a = np.transpose(img.buf, (0, 2, 1))
+    if squeeze is None:
+        squeeze = getattr(img, "squeeze", False)
+    return np.array(a[0] if squeeze else a)
+
+
+def to_device(x, device="cuda:0"):
+    """numpy (M,N)/(B,M,N) -> torch float64 CUDA tensor with column-major image memory."""
+    import torch
+    a = np.asarray(x, dtype=np.float64)
+    sq = a.ndim == 2
+    if sq:
+        a = a[None]
+    t = torch.from_numpy(np.ascontiguousarray(np.transpose(a, (0, 2, 1)))).to(device).permute(0, 2, 1)
+    return t[0] if sq else t
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def dvec(v, n):
+    """host double array of length n from a scalar or a sequence."""
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)))
+    return a, a.ctypes.data_as(_P)
