@@ -99,6 +99,13 @@ def load_library():
     with _lib_lock:
         if _lib is not None:
             return _lib
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process do not
+        # share the device.  Import torch FIRST (when present) so that libsbtv's DT_NEEDED
+        # libamdhip64.so.7 resolves to the copy torch already loaded and both use one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
@@ -135,9 +142,13 @@ class Context:
         except Exception:
             pass
 
-    def check(self, rc):
+    def check(self, rc, flags=0):
+        """Raise on a non-zero status.  With device pointers the C call is asynchronous on the
+        context stream: wait for it so that torch (which runs on its own stream) may read the result."""
         if rc != 0:
             raise SbtvError(rc, self.lib.sbtv_last_error(self.h).decode())
+        if flags & SBTV_DEVICE_PTRS:
+            self.sync()
 
     def sync(self):
         self.check(self.lib.sbtv_ctx_sync(self.h))
@@ -196,10 +207,12 @@ class Images:
             if x.dim() == 2:
                 x = x.unsqueeze(0)
             B, M, N = x.shape
-            if x.stride() != (M * N, 1, M):
+            st = x.stride()
+            if st[1:] != (1, M) or (B > 1 and st[0] != M * N):
                 raise ValueError("device images must be column-major per image: use sbtv.to_device()")
             if not x.is_cuda:
                 raise ValueError("torch images must live on the GPU (numpy arrays are the host path)")
+            __import__("torch").cuda.current_stream(x.device).synchronize()   # producer kernels done
             self.t = x
             self.B, self.M, self.N = B, M, N
             self.ptr = _P(x.data_ptr())

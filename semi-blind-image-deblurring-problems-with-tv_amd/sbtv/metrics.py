@@ -14,7 +14,7 @@ def _metric(fn_name, x_true, x, ctx=None):
     if (a.B, a.M, a.N) != (b.B, b.M, b.N) or a.flags != b.flags:
         raise ValueError("x_true and x must have the same shape and memory space")
     out = (C.c_double * a.B)()
-    ctx.check(getattr(ctx.lib, fn_name)(ctx.h, a.ptr, b.ptr, a.M, a.N, a.B, out, a.flags))
+    ctx.check(getattr(ctx.lib, fn_name)(ctx.h, a.ptr, b.ptr, a.M, a.N, a.B, out, a.flags), a.flags)
     return float(out[0]) if a.B == 1 else np.array(out[:])
 
 

@@ -86,7 +86,7 @@ class BlurOperator:
         taps = self._cm(xi.B)
         mu_a, mu_p = (None, None) if mu is None else L.dvec(mu, xi.B)
         ctx.check(ctx.lib.sbtv_A_wrapper(ctx.h, taps.ctypes.data_as(C.c_void_p), self.taille, mu_p, xi.ptr, out.ptr,
-                                         xi.M, xi.N, xi.B, int(mode), xi.flags))
+                                         xi.M, xi.N, xi.B, int(mode), xi.flags), xi.flags)
         sq = (x.dim() == 2) if xi.torch else xi.squeeze
         return L.images_result(out, sq)
 
@@ -149,7 +149,7 @@ def rfft2_packed(x, inverse=False, ctx=None):
     ctx = ctx or L.default_context()
     xi = L.Images(x)
     out = L.empty_like_images(xi)
-    ctx.check(ctx.lib.sbtv_rfft2_packed(ctx.h, xi.ptr, out.ptr, xi.M, xi.N, xi.B, 1 if inverse else 0, xi.flags))
+    ctx.check(ctx.lib.sbtv_rfft2_packed(ctx.h, xi.ptr, out.ptr, xi.M, xi.N, xi.B, 1 if inverse else 0, xi.flags), xi.flags)
     return out.buf if not out.torch else out.t     # raw (B, N, M) memory for numpy
 
 

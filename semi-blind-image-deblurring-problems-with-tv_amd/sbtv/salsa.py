@@ -95,7 +95,7 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
     ctx.check(ctx.lib.sbtv_SALSA_v2(ctx.h, yi.ptr, M, N, B, vp(taps), A.taille, tau_p, mu_p, C.byref(so),
                                     ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr,
                                     vp(objective), vp(distance), vp(times), vp(mses) if ti else None,
-                                    numA, numAt, nout, yi.flags))
+                                    numA, numAt, nout, yi.flags), yi.flags)
     sq = (y.dim() == 2) if yi.torch else yi.squeeze
     x = L.images_result(xo, sq)
     n = np.array(nout[:])

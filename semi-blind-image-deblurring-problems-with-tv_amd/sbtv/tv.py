@@ -74,7 +74,7 @@ def chambolle_prox_TV_stop(g, *varargin, ctx=None, return_info=False, **kw):
     k = (C.c_int * B)()
     err = (C.c_double * B)()
     ctx.check(ctx.lib.sbtv_chambolle_prox_TV_stop(ctx.h, gi.ptr, M, N, B, lam_p, maxiter, tol, tau, warm,
-                                                  px.ptr, py.ptr, f.ptr, k, err, gi.flags))
+                                                  px.ptr, py.ptr, f.ptr, k, err, gi.flags), gi.flags)
     sq = (g.dim() == 2) if gi.torch else gi.squeeze
     res = (L.images_result(f, sq), L.images_result(px, sq), L.images_result(py, sq))
     if return_info:
@@ -87,7 +87,7 @@ def TVnorm(x, ctx=None):
     ctx = ctx or L.default_context()
     xi = L.Images(x)
     out = (C.c_double * xi.B)()
-    ctx.check(ctx.lib.sbtv_TVnorm(ctx.h, xi.ptr, xi.M, xi.N, xi.B, out, xi.flags))
+    ctx.check(ctx.lib.sbtv_TVnorm(ctx.h, xi.ptr, xi.M, xi.N, xi.B, out, xi.flags), xi.flags)
     if xi.B == 1 and (getattr(xi, "squeeze", False) or (xi.torch and x.dim() == 2)):
         return float(out[0])
     return np.array(out[:])
