@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SALSA outer-iterations/s (+ final PSNR) on 2048x2048 Gaussian-blur TV deblurring.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one SALSA_v2 outer iteration (SALSA/SALSA_v2.m:423-494: warm-started 10-iteration
+Chambolle TV prox + the FFT least-squares step + residual / objective / mse / distance scalars and
+the host-side stopping rule) on one 2048x2048 image per GPU, inputs resident in HBM.  Exactly K
+steps are timed by running SALSA_v2 with MAXITERA = K and a tolerance that is never met; the timed
+region is the whole C-ABI call (it includes the one-time operator set-up, ~1 step's worth).
+Multi-GPU: independent images shard across ranks (no data-path collective, weak scaling); RCCL is
+used only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` for the dominant kernel (the Chambolle
+iteration), `cpu_baseline` (the NumPy oracle timed on the host cores, N=1 only), `final_psnr_db`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd")
+sys.path.insert(0, PKG)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SIZE = 2048
+THETA = 0.03
+W_TRUE = (0.4, 0.3)
+
+
+def make_problem(seed):
+    """2048^2 synthetic image (man.png tiled 4x4), Gaussian PSF, BSNR 30 dB — SURVEY.md §8d.
+    Data synthesis uses NumPy FFTs on the host (set-up, not the measured path)."""
+    import numpy as np
+    man = np.load(os.path.join(ROOT, "tests", "golden", "man_512.npy")).astype(np.float64)
+    x = np.tile(man, (SIZE // 512, SIZE // 512))
+    # Gaussian_psf (utils/Gaussian_psf.m) taps, blur = circular conv with taps at the top-left (resize.m)
+    g = np.arange(-3, 4.0)
+    V, U = np.meshgrid(g, g, indexing="ij")
+    k = (W_TRUE[0] * W_TRUE[1] / (2 * np.pi)) * np.exp(-(W_TRUE[0] ** 2 * U ** 2 + W_TRUE[1] ** 2 * V ** 2) / 2)
+    k /= k.sum()
+    h = np.zeros_like(x)
+    h[:7, :7] = k
+    Ax = np.real(np.fft.ifft2(np.fft.fft2(h) * np.fft.fft2(x)))
+    sigma = np.linalg.norm(Ax - Ax.mean()) / np.sqrt(x.size * 10 ** (30 / 10))      # run_Gaussian_demo.m:148
+    noise = np.random.default_rng(seed).standard_normal(x.shape)
+    return x, Ax + sigma * noise, sigma, noise
+
+
+def psnr(x, y):
+    import numpy as np
+    return 10 * np.log10(x.max() ** 2) - 10 * np.log10(np.sum((x - y) ** 2) / x.size)   # utils/PSNR.m
+
+
+def cpu_baseline(x, noise, budget_s=20.0):
+    """The oracle (op-for-op NumPy restatement incl. the reference's redundant FFTs) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sbtv_oracle as o
+    st = o.demo_setup("gaussian", x, noise, evMax=1.0)
+    res = o.salsa_from_estimates(st, THETA, W_TRUE, st["sigma"] ** 2, tol=0.0, outeriters=500, max_time=budget_s)
+    n = res["n_outer"]
+    return {"value": n / res["wall_loop"], "unit": "SALSA outer-iterations/s", "cores": o.get_workers(),
+            "kind": "port",
+            "sample": f"{n} outer iterations of the same 2048x2048 problem ({res['wall_loop']:.1f} s); "
+                      f"scipy.fft on {o.get_workers()} threads, NumPy element-wise passes single-threaded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import sbtv
+
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))   # RCCL
+
+    ctx = sbtv.Context(local_rank)
+    x, y, sigma, noise = make_problem(seed=1 + rank)      # each rank deblurs its own image
+    yd, xd = sbtv.to_device(y, dev), sbtv.to_device(x, dev)
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, *W_TRUE), ctx=ctx)
+    mu, tau = THETA / 10, THETA * sigma ** 2
+
+    def solve(maxit, tol):
+        return sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "StopCriterion", 1,
+                             "ToleranceA", tol, "MAXITERA", maxit, "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    # untimed: converged solve for the PSNR half of the metric (reference settings: tol 1e-5, <= 500 its)
+    xg, numA, numAt, obj, dist_, times, mses = solve(500, 1e-5)
+    final_psnr = psnr(x, sbtv.to_host(xg))
+    n_conv = len(obj) - 1
+
+    if args.warmup > 0:
+        solve(args.warmup, -1.0)
+    barrier()
+    t0 = time.perf_counter()
+    out = solve(args.steps, -1.0)          # tolA < 0: the stop rule never fires -> exactly K outer iterations
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert len(out[3]) - 1 == args.steps
+    tm = ctx.last_timing()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        launches = tm["chambolle_launches"]
+        avg_ms = tm["chambolle_ms"] / max(launches, 1)
+        alg_bytes = 40.0 * SIZE * SIZE                       # read g,px,py + write px,py per iteration
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_chambolle.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "SALSA outer-iters/sec + final PSNR, 2048x2048 Gaussian blur",
+            "value": value, "unit": "SALSA outer-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SALSA_v2 TV deblur (TViters=10, mu=theta/10, tau=theta*sigma^2, theta=0.03), "
+                                   "one 2048x2048 image per GPU (man.png tiled 4x4), Gaussian PSF 7x7 w=(0.4,0.3), "
+                                   "BSNR 30 dB; independent images shard across GPUs",
+                       "image": [SIZE, SIZE], "images_per_gpu": 1, "parallelism": f"images x{world}"},
+            "final_psnr_db": final_psnr, "outer_iterations_to_tol_1e-5": n_conv,
+            "loop_ms_per_step_device": tm["loop_ms"] / args.steps,
+            "roofline": {"kernel": "chambolle_iter_kernel", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(x, noise, args.cpu_budget)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -501,7 +501,7 @@ def SALSA_v2(y, A, tau, mu=1e-3, AT=None, invLS=None, true_x=None,
         times.append(time.process_time() - t0)               # :493
         if max_time is not None and time.perf_counter() - wall0 > max_time:
             break
-    return dict(x=x, numA=numA, numAt=numAt, objective=np.array(objective),
+    return dict(x=x, numA=numA, numAt=numAt, objective=np.array(objective), wall_loop=time.perf_counter() - wall0,
                 distance=np.array(distance), times=np.array(times),
                 mses=np.array(mses), n_outer=n_outer, u=u, bu=bu, pux=pux, puy=puy,
                 criterion=np.array(criterion))
