@@ -20,6 +20,8 @@ struct ProxCtrl {
     int done;      // 1: stop rule met -> iteration kernels return at once
     int cur;       // which dual ping-pong buffer holds the current (px,py)
     int maxiter;
+    int redo;      // >0: the last fused launch over-ran the stop rule; re-run that many steps from `cur`
+    int pad;
     double err;    // last err (chambolle_prox_TV_stop.m:128)
     double lambda;
     double tol;
@@ -103,7 +105,8 @@ int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count,
 // ----------------------------- TV kernels (tv.hip) --------------------------
 struct ProxPlan {
     int M, N, batch;
-    int tiles_i, tiles_j, nblk;   // blocks per image
+    int tiles_i, tiles_j, nblk;   // blocks per image (one-iteration kernels)
+    int ftiles_i, ftiles_j, fnblk; // blocks per image (temporally fused kernel)
     ProxCtrl *ctrl;               // [batch]
     double *pbuf;                 // [2 pingpong][2 (px,py)][batch][M*N]
     double *partials;             // [batch][nblk]

@@ -195,6 +195,106 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
     if (threadIdx.x == 0) partials[(size_t)b * (gridDim.x * gridDim.y) + (size_t)tj * tiles_i + ti] = bs;
 }
 
+// ---------------------------------------------------------------------------
+// Temporally fused Chambolle kernel: up to FH iterations per launch.
+//
+// A workgroup (4 wave64) owns a REGION of FRI=128 rows x FRJ=64 columns that is
+// the CORE tile (116 x 52) plus a halo of FH=6 pixels on every side; one
+// iteration has a dependency radius of one pixel, so after s <= FH iterations
+// the core is still exact.  The whole state of the region lives in REGISTERS:
+// lane l of wave w owns the row pair (2l, 2l+1) of the FCJ=16 columns
+// [16w, 16w+16) : px, py and g/lambda = 96 doubles per lane.  Row neighbours
+// come from the adjacent lanes through DPP wave shifts (no LDS, no memory);
+// column neighbours are in the same lane's registers except at the three
+// wave seams, which exchange one column of u / py per iteration through LDS.
+// HBM traffic per launch is one read of (g,px,py) over the region and one
+// write of (px,py) over the core, for up to 6 iterations of work.
+//
+// The stop rule of chambolle_prox_TV_stop.m:131 is evaluated after the launch
+// from per-iteration error partials; if it fired in the middle of a launch the
+// control kernel records `redo` and a (normally empty) re-run launch repeats
+// exactly that many steps from the untouched input buffer, so results are
+// identical to one-iteration-at-a-time execution.
+// ---------------------------------------------------------------------------
+constexpr int FH = 6;                    // halo = max fused iterations
+constexpr int FNW = 4;                   // waves per block
+constexpr int FRI = 128;                 // region rows
+constexpr int FCI = FRI - 2 * FH;        // core rows   (116)
+// columns per wave (CJ) is a tuning parameter: region columns = 4 CJ, core columns = 4 CJ - 2 FH
+struct FusedVariant { int cj; int minw; int fast; };
+static FusedVariant g_fused = {8, 2, 1};
+static inline int fused_core_cols() { return g_fused.cj * FNW - 2 * FH; }
+
+__device__ __forceinline__ double dpp_from_prev_lane(double v) {   // lane l gets lane l-1 (lane 0: 0)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_next_lane(double v) {   // lane l gets lane l+1 (lane 63: 0)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+#include "tv_fused.inc"
+
+// Stop rule after a fused launch of `steps_arg` iterations (see the kernel header).
+__global__ __launch_bounds__(256) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
+                                                                    const double *__restrict__ partials, int nblk,
+                                                                    int steps_arg, int redo_mode) {
+    const int b = blockIdx.x;
+    ProxCtrl *c = &ctrl[b];
+    __shared__ double red[4];
+    __shared__ double tots[FH];
+    int nsteps;
+    if (redo_mode) {
+        if (c->redo <= 0) return;
+        nsteps = c->redo;
+    } else {
+        if (c->done) return;
+        nsteps = min(steps_arg, c->maxiter - c->k);
+        if (nsteps <= 0) return;
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const double *p = partials + ((size_t)b * FH + s) * nblk;
+        double acc = 0.0;
+        for (int q = threadIdx.x; q < nblk; q += 256) acc += p[q];
+        const double tot = block_sum_256(acc, red);
+        if (threadIdx.x == 0) tots[s] = tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (redo_mode) {
+            c->k += nsteps;
+            c->err = sqrt(tots[nsteps - 1]);
+            c->cur ^= 1;
+            c->redo = 0;
+            return;
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            const int k = c->k + s + 1;
+            const double err = sqrt(tots[s]);
+            const bool stop = !((k < c->maxiter) && (err > c->tol));
+            if (stop) {
+                c->done = 1;
+                if (s == nsteps - 1) {
+                    c->k = k;
+                    c->err = err;
+                    c->cur ^= 1;
+                } else {
+                    c->redo = s + 1;       // over-ran: p in the output buffer is too far; re-run s+1 steps
+                }
+                return;
+            }
+        }
+        c->k += nsteps;
+        c->err = sqrt(tots[nsteps - 1]);
+        c->cur ^= 1;
+    }
+}
+
 // Sum the per-block partials in a fixed order, then apply the stop rule
 // cont = (k < MaxIter) & (err > tol)   (chambolle_prox_TV_stop.m:131)
 __global__ __launch_bounds__(256) void chambolle_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
@@ -227,6 +327,8 @@ __global__ void prox_reset_kernel(ProxCtrl *__restrict__ ctrl, const double *__r
     c.done = (frozen && frozen[b]) ? 1 : 0;
     if (!keep_cur) c.cur = 0;
     c.maxiter = maxiter;
+    c.redo = 0;
+    c.pad = 0;
     c.err = 0.0;
     c.lambda = lambda[b] * lambda_scale;
     c.tol = tol;
@@ -342,10 +444,30 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl) {
     pl->tiles_i = (M + TI - 1) / TI;
     pl->tiles_j = (N + TJ - 1) / TJ;
     pl->nblk = pl->tiles_i * pl->tiles_j;
+    pl->ftiles_i = (M + FCI - 1) / FCI;
+    {
+        static bool init = false;
+        if (!init) {
+            init = true;
+            if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,minw"
+                int cj = 0, mw = 0;
+                if (sscanf(e, "%d,%d", &cj, &mw) == 2 && (cj == 8 || cj == 12 || cj == 16) && (mw == 1 || mw == 2)) {
+                    g_fused.cj = cj;
+                    g_fused.minw = mw;
+                }
+            }
+            // SBTV_EXACT=1: IEEE div/sqrt, no FMA contraction (validation build of the arithmetic)
+            if (getenv("SBTV_EXACT") != nullptr) g_fused.fast = 0;
+        }
+    }
+    pl->ftiles_j = (N + fused_core_cols() - 1) / fused_core_cols();
+    pl->fnblk = pl->ftiles_i * pl->ftiles_j;
     const size_t P = (size_t)M * N;
+    size_t npart = (size_t)batch * pl->nblk;
+    if ((size_t)batch * FH * pl->fnblk > npart) npart = (size_t)batch * FH * pl->fnblk;
     SBTV_TRY(ws_get_t(ctx, "prox.ctrl", (size_t)batch, &pl->ctrl));
     SBTV_TRY(ws_get_t(ctx, "prox.pbuf", 4 * P * batch, &pl->pbuf));
-    SBTV_TRY(ws_get_t(ctx, "prox.partials", (size_t)batch * pl->nblk, &pl->partials));
+    SBTV_TRY(ws_get_t(ctx, "prox.partials", npart, &pl->partials));
     return 0;
 }
 
@@ -380,9 +502,44 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py) {
     return 0;
 }
 
+int g_force_single_step = 0;   // test hook (SBTV_SINGLE_STEP=1): one-iteration kernels only
+
 int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter) {
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
     const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
+    static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
+    if (v && !env_single && !g_force_single_step) {
+        // temporally fused path: ceil(K/FH) launches of (nearly) equal step counts + the redo pair
+        const dim3 fgrid(pl.ftiles_i, pl.ftiles_j, pl.batch);
+        const int nl = (maxiter + FH - 1) / FH;
+        const int base = maxiter / nl, extra = maxiter % nl;
+        auto launch_fused = [&](int steps, int redo) {
+#define SBTV_FUSED_CASE(CJ_, MW_)                                                                                    \
+    if (g_fused.cj == CJ_ && g_fused.minw == MW_) {                                                                  \
+        if (g_fused.fast)                                                                                            \
+            hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, MW_, true>), fgrid, dim3(64 * FNW), 0, ctx->stream, g,   \
+                               pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps,    \
+                               redo);                                                                                \
+        else                                                                                                         \
+            hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, MW_, false>), fgrid, dim3(64 * FNW), 0, ctx->stream, g,  \
+                               pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps,    \
+                               redo);                                                                                \
+    }
+            SBTV_FUSED_CASE(8, 2)
+            SBTV_FUSED_CASE(12, 2)
+            SBTV_FUSED_CASE(16, 2)
+            SBTV_FUSED_CASE(8, 1)
+            SBTV_FUSED_CASE(12, 1)
+            SBTV_FUSED_CASE(16, 1)
+#undef SBTV_FUSED_CASE
+            hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(256), 0, ctx->stream, pl.ctrl,
+                               pl.partials, pl.fnblk, steps, redo);
+        };
+        for (int l = 0; l < nl; ++l) launch_fused(base + (l < extra ? 1 : 0), 0);
+        launch_fused(0, 1);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     for (int it = 0; it < maxiter; ++it) {
         if (v)
             hipLaunchKernelGGL(chambolle_iter_kernel<true>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl,
