@@ -310,6 +310,7 @@ struct RowsParams {
     const int *frozen;
     int n1;                 // rows of S per image
     int fwd, inv, op;
+    int shared_spec;        // 1: H / Y / D1 / D2 hold ONE spectrum shared by every image of the batch
 };
 
 template <int OP>
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
 
     double acc[3] = {0.0, 0.0, 0.0};
     if constexpr (OP != OP_NONE) {
-        const size_t hbase = (size_t)b * (n1 + 1) * N;
+        const size_t hbase = p.shared_spec ? 0 : (size_t)b * (n1 + 1) * N;
         const double mu = p.mu ? p.mu[b] : 0.0;
         constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF);
         constexpr bool needD = (OP == OP_GRAD);
@@ -618,6 +619,7 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.fwd = a.dir_fwd;
     p.inv = a.dir_inv;
     p.op = a.op;
+    p.shared_spec = a.shared_spec;
     const int L = ilog2(pl.N);
     if (L > 11) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 2048");
     if (pl.N >= 512) {

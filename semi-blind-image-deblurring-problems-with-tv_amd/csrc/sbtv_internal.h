@@ -163,6 +163,7 @@ struct RowsArgs {
     const double *mu;       // per image (device)
     double *acc;            // partial sums [batch][3][nblk_rows]
     const int *frozen;      // optional per-image flag: skip image when set
+    int shared_spec;        // 1: one spectrum set shared by the whole batch (parallel chains on one image)
 };
 int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout, const RowsArgs &a);
 int fft_rows_blocks(const FftPlan &pl);   // number of row blocks per image (acc stride)

@@ -11,8 +11,13 @@ from .operators import (BlurOperator, A_wrapper, Gaussian_psf, psf_gaussian, psf
                         rfft2_packed, unpack_half_spectrum)
 from .salsa import SALSA_v2
 from .metrics import PSNR, MSE
+from .fista import my_fista, my_deblur_fista, Psi_TV
+from .sapg import (SAPG_algorithm_Guassian, SAPG_algorithm_moffat, SAPG_algorithm_laplace, max_eigenval,
+                   demo_setup)
 
 __all__ = [
+    "my_fista", "my_deblur_fista", "Psi_TV", "SAPG_algorithm_Guassian", "SAPG_algorithm_moffat",
+    "SAPG_algorithm_laplace", "max_eigenval", "demo_setup",
     "Context", "SbtvError", "default_context", "load_library", "to_device", "to_host", "LIB_PATH",
     "chambolle_prox_TV_stop", "TVnorm", "BlurOperator", "A_wrapper", "Gaussian_psf", "psf_gaussian",
     "psf_moffat", "psf_laplace", "psf_family", "rfft2_packed", "unpack_half_spectrum", "SALSA_v2", "PSNR", "MSE",

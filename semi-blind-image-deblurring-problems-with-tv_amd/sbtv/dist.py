@@ -1,0 +1,113 @@
+"""Multi-GPU layer: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU-only hosts for tests).
+
+The hot path shards by independent units:
+  * images of a batch        -> image i runs on rank i mod world, no data-path collective;
+                                one gather of per-image scalars at the end;
+  * MYULA chains on ONE image -> chains split over ranks; per SAPG iteration ONE all-reduce(sum)
+                                of 5 doubles [sum G_theta, sum G_p0, sum G_p1, sum G_sigma, n_chains]
+                                (the reference's `mean(g_*)`, SAPG_algorithm_moffat.m:158-173);
+  * a single image is never split across GPUs (global FFT / TV halo exchange): replicas only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (idempotent)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        kw["device_id"] = torch.device(f"cuda:{lr}")
+    dist.init_process_group(backend, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard(n_items, rank=None, world=None):
+    """Indices of the items this rank owns: item i -> rank i mod world."""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    return list(range(rank, n_items, world))
+
+
+def split_chains(n_chains, rank=None, world=None):
+    """Number of MYULA chains this rank runs and the index of its first chain (for the RNG streams)."""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    base, extra = divmod(n_chains, world)
+    mine = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return mine, first
+
+
+def gather_objects(obj):
+    """All ranks' per-item results (small python objects: scalars per image) on every rank."""
+    import torch.distributed as dist
+    r, w = rank_world()
+    if w == 1:
+        return [obj]
+    out = [None] * w
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def merge_sharded(n_items, per_rank_lists):
+    """Inverse of `shard`: per_rank_lists[r][k] is the result of item r + k*world."""
+    world = len(per_rank_lists)
+    out = [None] * n_items
+    for r, lst in enumerate(per_rank_lists):
+        for k, v in enumerate(lst):
+            out[r + k * world] = v
+    return out
+
+
+def make_allreduce_fn():
+    """A `reduce_fn` for sbtv_SAPG_algorithm(share_gradients=1): sums `buf[0:n]` over all ranks in place.
+    RCCL needs a device tensor; the payload is 40 bytes, so the staging copy is noise."""
+    import torch
+    import torch.distributed as dist
+    r, w = rank_world()
+    if w == 1:
+        return None
+    use_cuda = dist.get_backend() == "nccl"
+
+    def fn(user, buf, n):
+        try:
+            t = torch.tensor([buf[i] for i in range(n)], dtype=torch.float64)
+            if use_cuda:
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t = t.cpu()
+            for i in range(n):
+                buf[i] = float(t[i])
+            return 0
+        except Exception:      # never raise through the C boundary
+            return 1
+    return fn
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,201 @@
+"""Host mirror of SAPG/SAPG_algorithm_{Guassian,moffat,laplace}.m, utils/max_eigenval_*.m and the
+data-synthesis / step-size block of run_*_demo.m, over the device-resident MYULA/SAPG loop.
+
+`op` is the reference's option struct (a dict or any attribute bag with the same field names);
+its function handles (op.gradF, op.proxG, op.logPi, ...) are not used: the C-ABI rebuilds them
+from the PSF family, `y` and the scalar fields.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .operators import BlurOperator, psf_family
+
+_KIND = {"gaussian": 0, "moffat": 1, "laplace": 2}
+
+
+def _get(op, name, default=None):
+    if isinstance(op, dict):
+        return op.get(name, default)
+    return getattr(op, name, default)
+
+
+def max_eigenval(A, At, params, im_size, tol, max_iter, verbose=0, x0=None, ctx=None):
+    """val = max_eigenval(A, At, a, b, im_size, tol, max_iter, verbose)
+    (utils/max_eigenval_Gaussian_Moffat.m:1-27, utils/max_eigenval_Laplace.m:1-28).
+    A: callable (x, *params) -> BlurOperator application is not needed: pass A as a
+    sbtv.BlurOperator built at `params` (At is then ignored).  x0: start vector
+    (the reference draws randn(im_size); MATLAB's stream is unpinned -> pass it explicitly)."""
+    ctx = ctx or L.default_context()
+    if not isinstance(A, BlurOperator):
+        raise TypeError("A must be a sbtv.BlurOperator built at the requested parameters")
+    if x0 is None:
+        x0 = np.random.default_rng(0).standard_normal(im_size)
+    xi = L.Images(x0)
+    taps = A._cm(1)
+    val = C.c_double(0.0)
+    it = C.c_int(0)
+    ctx.check(ctx.lib.sbtv_max_eigenval(ctx.h, taps.ctypes.data_as(C.c_void_p), A.taille, xi.ptr, xi.M, xi.N,
+                                        float(tol), int(max_iter), C.byref(val), C.byref(it), xi.flags), xi.flags)
+    if verbose:
+        print(f"Norm = {val.value:e} ({it.value} iterations)")
+    return val.value
+
+
+def demo_setup(kind, x, noise, evMax, BSNR=30.0, true_params=None, BSNR_min=None, BSNR_max=None, lambdaMax=None,
+               gammaFrac=0.98, th_init=0.01, ctx=None):
+    """The observation model and MYULA step sizes of run_Gaussian_demo.m:145-184,
+    run_moffat_demo.m:139-176, run_laplace_demo.m:109-142 (blur on the GPU, scalars on the host).
+    Returns a dict with y, sigma, sigma_min/max/init (variances), Lf, lambda, gamma."""
+    defaults = {"gaussian": dict(true=(0.4, 0.3), bmin=15, bmax=45, lmax=2.0, lf=min, gmul=1.0),
+                "moffat": dict(true=(0.4, 3.5), bmin=18, bmax=35, lmax=2.0, lf=min, gmul=1.0),
+                "laplace": dict(true=(0.3,), bmin=15, bmax=45, lmax=0.1, lf=max, gmul=10.0)}[kind]
+    p = tuple(defaults["true"] if true_params is None else true_params)
+    bmin = defaults["bmin"] if BSNR_min is None else BSNR_min
+    bmax = defaults["bmax"] if BSNR_max is None else BSNR_max
+    lmax = defaults["lmax"] if lambdaMax is None else lambdaMax
+    x = np.asarray(x, dtype=np.float64)
+    taps, _ = psf_family(kind, 7, p)
+    Ax = BlurOperator(taps, ctx=ctx).A(x)
+    dimX = x.size
+    nrm = float(np.linalg.norm(Ax - np.mean(Ax)))
+    sigma = nrm / math.sqrt(dimX * 10 ** (BSNR / 10))
+    smin = nrm / math.sqrt(dimX * 10 ** (bmin / 10))
+    smax = nrm / math.sqrt(dimX * 10 ** (bmax / 10))
+    y = Ax + sigma * np.asarray(noise, dtype=np.float64)
+    lf = lambda s2: evMax ** 2 / s2
+    Lf = defaults["lf"](lf(smin ** 2), lf(smax ** 2))
+    lam = min(5 / Lf, lmax)
+    gamma = defaults["gmul"] * gammaFrac * (1 / (Lf + 1 / lam))
+    return dict(kind=kind, y=y, x=x, sigma=sigma, sigma_min=smin ** 2, sigma_max=smax ** 2,
+                sigma_init=(smin ** 2 + smax ** 2) / 2, Lf=Lf, **{"lambda": lam}, gamma=gamma, p_true=p,
+                th_init=th_init, dimX=dimX)
+
+
+def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=None, ctx=None):
+    ctx = ctx or L.default_context()
+    yi = L.Images(y)
+    B, M, N = yi.B, yi.M, yi.N
+    o = L.sbtv_sapg_opts()
+    o.kind = _KIND[kind]
+    o.psf_size = int(_get(op, "psf_size", 7))
+    o.samples = int(_get(op, "samples"))
+    o.warmup = int(_get(op, "warmup", 100))                       # default 100 (SAPG_algorithm_Guassian.m:20)
+    o.burnIn = int(_get(op, "burnIn"))
+    o.chambolleit = int(_get(op, "chambolleit", 25))              # run_Gaussian_demo.m:188
+    o.share_gradients = 1 if share_gradients else 0
+    o.lambda_ = float(c.get("lam", 1.0)) * float(_get(op, "lambda"))     # lamb = c.lam*op.lambda (:30)
+    o.gamma = float(c.get("gam", 1.0)) * float(_get(op, "gamma"))
+    o.th_init = float(_get(op, "th_init"))
+    o.min_th = float(_get(op, "min_th"))
+    o.max_th = float(_get(op, "max_th"))
+    names = {"gaussian": ("w1", "w2"), "moffat": ("alpha", "beta"), "laplace": ("b",)}[kind]
+    for q, nm in enumerate(names):
+        o.p_init[q] = float(_get(op, nm + "_init"))
+        o.p_min[q] = float(_get(op, "min_" + nm))
+        o.p_max[q] = float(_get(op, "max_" + nm))
+        o.p_true[q] = float(np.ravel(_get(op, nm))[0])
+        o.fix_p[q] = int(bool(_get(op, "fix_" + nm, 0)))
+        o.c_p[q] = float(c[nm])
+    if len(names) == 1:
+        o.fix_p[1] = 1
+    o.phi = float(_get(op, "phi", 0.0))
+    o.fix_sigma = int(bool(_get(op, "fix_sigma", 0)))
+    o.sigma2_true = float(_get(op, "sigma")) ** 2                 # sigma = op.sigma^2 (:49)
+    o.sigma2_init = float(_get(op, "sigma_init"))
+    o.sigma2_min = float(_get(op, "sigma_min"))
+    o.sigma2_max = float(_get(op, "sigma_max"))
+    o.d_scale = float(_get(op, "d_scale"))
+    o.d_exp = float(_get(op, "d_exp"))
+    o.c_theta = float(c["theta"])
+    o.c_sigma = float(c["sigma"])
+    o.seed = int(_get(op, "seed", 1))
+    S, W = o.samples, max(o.warmup, 1)
+    nch = B
+    thetas = np.zeros((nch, S)); sigmas = np.zeros((nch, S)); ps = np.zeros((nch, 2, S))
+    logpi = np.zeros((nch, S)); logpi_wu = np.zeros((nch, W)); gx = np.zeros((nch, S)); grads = np.zeros((nch, 4, S))
+    eb = np.zeros((nch, 4))
+    xl = L.empty_like_images(yi)
+    x0i = L.Images(x0) if x0 is not None else None
+    if _get(op, "X0") is not None and x0 is None:
+        x0i = L.Images(_get(op, "X0"))
+    nz_ptr, nz_keep = None, None
+    if noise is not None:
+        if L._is_torch(noise):
+            nz_keep = noise
+            nz_ptr = C.c_void_p(noise.data_ptr())
+        else:
+            a = np.asarray(noise, dtype=np.float64)           # (steps, B, M, N) or (steps, M, N)
+            if a.ndim == 3:
+                a = a[:, None]
+            nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))     # column-major images
+            nz_ptr = nz_keep.ctypes.data_as(C.c_void_p)
+    cb = L.ALLREDUCE_FN(reduce_fn) if reduce_fn is not None else L.ALLREDUCE_FN()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    yptr = yi.ptr
+    if share_gradients:
+        # all chains sample ONE image: y is a single image, the batch size is the chain count
+        nch = int(_get(op, "chains", 1))
+        thetas = np.zeros((nch, S)); sigmas = np.zeros((nch, S)); ps = np.zeros((nch, 2, S))
+        logpi = np.zeros((nch, S)); logpi_wu = np.zeros((nch, W)); gx = np.zeros((nch, S)); grads = np.zeros((nch, 4, S))
+        eb = np.zeros((nch, 4))
+        if yi.torch:
+            import torch
+            xl = L.Images(torch.empty((nch, N, M), dtype=torch.float64, device=yi.t.device).permute(0, 2, 1))
+        else:
+            xl = L.Images(np.zeros((nch, M, N)))
+    ctx.check(ctx.lib.sbtv_SAPG_algorithm(ctx.h, yptr, M, N, nch, C.byref(o), x0i.ptr if x0i else None, nz_ptr,
+                                          vp(thetas), vp(ps), vp(sigmas), vp(logpi), vp(logpi_wu), vp(gx), vp(grads),
+                                          vp(eb), xl.ptr, cb, None, yi.flags), yi.flags)
+    results = []
+    for b in range(nch):
+        r = dict(theta_EB=eb[b, 0], sigma_EB=eb[b, 3], last_samp=S, thetas=thetas[b], sigmas=sigmas[b],
+                 logPiTraceX=logpi[b], logPiTrace_WU=logpi_wu[b, :o.warmup] if o.warmup > 0 else np.array([]),
+                 gXTrace=gx[b], grad_theta=grads[b, 0], grad_sigma=grads[b, 3], last_theta=thetas[b, -1],
+                 last_sigma=sigmas[b, -1], c_theta=o.c_theta, c_sigma=o.c_sigma, options=op)
+        for q, nm in enumerate(names):
+            r[nm + "_EB"] = eb[b, 1 + q]
+            r[nm + "s"] = ps[b, q]
+            r["last_" + nm] = ps[b, q, -1]
+            r["grad_" + nm] = grads[b, 1 + q]
+        results.append(r)
+    xs = L.images_result(xl, False)
+    for b in range(nch):
+        results[b]["Xlast_sample"] = xs[b]
+    return results
+
+
+def _unpack(kind, res, batched):
+    names = {"gaussian": ("w1", "w2"), "moffat": ("alpha", "beta"), "laplace": ("b",)}[kind]
+    if not batched:
+        r = res[0]
+        return (r["theta_EB"],) + tuple(r[n + "_EB"] for n in names) + (r["sigma_EB"], r)
+    return ([r["theta_EB"] for r in res],) + tuple([r[n + "_EB"] for r in res] for n in names) + \
+        ([r["sigma_EB"] for r in res], res)
+
+
+def SAPG_algorithm_Guassian(y, op, c, **kw):
+    """[theta_EB, w1_EB, w2_EB, sigma_EB, results] = SAPG_algorithm_Guassian(y, op, c)
+    (SAPG/SAPG_algorithm_Guassian.m:7-308).  c: dict(theta, w1, w2, sigma, lam, gam) (run_Gaussian_demo.m:34-39)."""
+    res = _sapg("gaussian", y, op, c, **kw)
+    return _unpack("gaussian", res, len(res) > 1)
+
+
+def SAPG_algorithm_moffat(y, op, c=None, **kw):
+    """[theta_EB, alpha_EB, beta_EB, sigma2_EB, results] = SAPG_algorithm_moffat(y, op)
+    (SAPG/SAPG_algorithm_moffat.m:7-297; step scales hard-coded at :135-138)."""
+    c = c or dict(theta=0.1, alpha=10.0, beta=1e4, sigma=1e4, lam=1.0, gam=1.0)
+    res = _sapg("moffat", y, op, c, **kw)
+    return _unpack("moffat", res, len(res) > 1)
+
+
+def SAPG_algorithm_laplace(y, op, c=None, **kw):
+    """[theta_EB, b_EB, sigma2_EB, results] = SAPG_algorithm_laplace(y, op)
+    (SAPG/SAPG_algorithm_laplace.m:7-268; step scales hard-coded at :139-141)."""
+    c = c or dict(theta=0.01, b=100.0, sigma=1e4, lam=1.0, gam=1.0)
+    res = _sapg("laplace", y, op, c, **kw)
+    return _unpack("laplace", res, len(res) > 1)

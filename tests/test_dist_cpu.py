@@ -1,0 +1,70 @@
+"""CPU tests of the N>1 path: world_size-2 `gloo` process group exercising the sharding,
+the gather of per-image results and the all-reduce callback used by the multi-chain SAPG."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "semi-blind-image-deblurring-problems-with-tv_amd"))
+    from sbtv import dist as sd
+    r, w = sd.init("gloo")
+    assert (r, w) == (rank, world)
+    # 1) batch of 7 independent images: image i -> rank i mod world
+    mine = sd.shard(7)
+    local = [{"image": i, "theta_EB": 0.01 * (i + 1), "n_outer": 30 + i} for i in mine]
+    merged = sd.merge_sharded(7, sd.gather_objects(local))
+    # 2) 5 chains on one image: chain split + the per-iteration all-reduce of [G_t, G_p0, G_p1, G_s, n]
+    nch, first = sd.split_chains(5)
+    fn = sd.make_allreduce_fn()
+    buf = (C.c_double * 5)(*[float(first + k + 1) for k in range(4)], float(nch))
+    rc = fn(None, buf, 5)
+    sd.barrier()
+    q.put((rank, mine, merged, nch, first, rc, list(buf)))
+
+
+def test_world2_gloo_sharding_and_allreduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, mine0, merged0, n0, f0, rc0, b0), (r1, mine1, merged1, n1, f1, rc1, b1) = res
+    assert mine0 == [0, 2, 4, 6] and mine1 == [1, 3, 5]
+    assert merged0 == merged1 and [m["image"] for m in merged0] == list(range(7))
+    assert (n0, f0, n1, f1) == (3, 0, 2, 3)
+    assert rc0 == rc1 == 0 and b0 == b1
+    assert b0[4] == 5.0                                   # total number of chains
+    assert b0[0] == (0 + 1) + (3 + 1)                     # sums over ranks
+
+
+def test_single_process_helpers():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "semi-blind-image-deblurring-problems-with-tv_amd"))
+    from sbtv import dist as sd
+    assert sd.shard(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert sd.shard(64, 3, 8) == list(range(3, 64, 8))
+    assert [sd.split_chains(32, r, 8) for r in range(8)] == [(4, 4 * r) for r in range(8)]
+    assert sum(sd.split_chains(10, r, 4)[0] for r in range(4)) == 10
+    assert sd.merge_sharded(5, [[0, 2, 4], [1, 3]]) == [0, 1, 2, 3, 4]
+    assert sd.make_allreduce_fn() is None
