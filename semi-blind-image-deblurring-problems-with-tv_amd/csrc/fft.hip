@@ -362,7 +362,15 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     const int b = blockIdx.y;
     if (p.frozen && p.frozen[b]) return;
     const int q = threadIdx.x % RK, t = threadIdx.x / RK;
-    const int kb = blockIdx.x;
+    // XCD-aware row-block order (blockIdx % 8 names the group of workgroups sharing one L2): each
+    // group walks a contiguous range of row blocks, so the 128-byte lines that consecutive row
+    // blocks share (RK * 16 B < 128 B) are re-used from that L2.  Bijective for any block count.
+    int kb;
+    {
+        const int nt = gridDim.x, bid = blockIdx.x;
+        const int q8 = nt >> 3, r8 = nt & 7, x = bid & 7, o = bid >> 3;
+        kb = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + o;
+    }
     const int k = kb * RK + q;
     const int n1 = p.n1;
     const size_t ibase = (size_t)b * n1 * N;

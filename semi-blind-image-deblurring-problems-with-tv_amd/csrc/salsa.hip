@@ -1,8 +1,6 @@
-// Device-resident MAP solvers: SALSA_v2 (ADMM, SALSA/SALSA_v2.m:389-494) and
-// FISTA (SALSA/my_fista.m:5-56, my_deblur_fista.m:5-68) over the TV prox and
-// the spectral blur operator.  The host only sees a handful of scalars per
-// outer iteration (objective terms, mse, distance) and applies the stopping
-// rule; images never leave HBM.
+// Device-resident SALSA_v2 (ADMM, SALSA/SALSA_v2.m:389-494) over the TV prox and the spectral
+// blur operator.  The host only sees eight scalars per image and outer iteration (objective
+// terms, mse, distance) and applies the stopping rule; images never leave HBM.
 //
 // One SALSA outer iteration (fused form):
 //   u      = prox_{(tau/mu) TV}(x - bu)   warm-started duals       (:429)
@@ -10,7 +8,11 @@
 //   Xh     = (conj(H) Yh + mu S) / (|H|^2 + mu)                   (:434-436; ATy enters as conj(H) Yh)
 //   resid2 = sum |Yh - H Xh|^2 / (M N)          (Parseval for  :442-444, no second FFT pair)
 //   x      = irfft2(Xh)
-//   bu    += u - x ; g = x - bu ; sums for mse / distance           (:440,446-451)
+//   bu    += u - x ; g = x - bu ; sums for mse / distance / TVnorm(u)  (:440,444,446-451)
+//
+// Speculative pipelining: the host enqueues outer iteration k+1 before it has seen the scalars of
+// iteration k, so the GPU never waits for the stop-rule round trip.  x is double-buffered, hence
+// when iteration k turns out to be the last one its x is still intact (one wasted iteration).
 #include <chrono>
 #include <cmath>
 
@@ -19,48 +21,48 @@
 namespace sbtv {
 
 struct Collect {
-    // partial-sum sources of one outer iteration
-    const double *acc;      // rows kernel: [batch][3][nrb]
+    const double *acc;      // rows kernel partials: [batch][3][nrb]           -> resid2
     int nrb;
-    const double *tvp;      // tvnorm partials [batch][ntv]
+    const double *tvp;      // tvnorm partials [batch][ntv] (initial objective) or null -> post slot 5
     int ntv;
-    const double *post;     // post kernel partials [batch][5][npb]
+    const double *post;     // post kernel partials [batch][6][npb]
     int npb;
 };
 
-// one block per image: assemble SalsaScal from the partial arrays (fixed order)
+// grid (7, batch): block q reduces ONE quantity of SalsaScal (fixed order, deterministic)
 __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, const ProxCtrl *__restrict__ ctrl,
                                                              SalsaScal *__restrict__ out) {
     __shared__ double red[4];
-    const int b = blockIdx.x;
-    auto block_sum = [&](const double *p, int n) -> double {
-        double s = 0.0;
-        if (p)
-            for (int q = threadIdx.x; q < n; q += 256) s += p[q];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        return (red[0] + red[1]) + (red[2] + red[3]);
-    };
-    const double resid2 = block_sum(c.acc ? c.acc + ((size_t)b * 3) * c.nrb : nullptr, c.nrb);
-    const double tv = block_sum(c.tvp ? c.tvp + (size_t)b * c.ntv : nullptr, c.ntv);
-    double ps[5];
-    for (int q = 0; q < 5; ++q) ps[q] = block_sum(c.post ? c.post + ((size_t)b * 5 + q) * c.npb : nullptr, c.npb);
+    const int b = blockIdx.y, qn = blockIdx.x;
+    const double *p = nullptr;
+    int n = 0;
+    if (qn == 0) {
+        p = c.acc ? c.acc + ((size_t)b * 3) * c.nrb : nullptr;
+        n = c.nrb;
+    } else if (qn == 1) {
+        if (c.tvp) {
+            p = c.tvp + (size_t)b * c.ntv;
+            n = c.ntv;
+        } else if (c.post) {
+            p = c.post + ((size_t)b * 6 + 5) * c.npb;
+            n = c.npb;
+        }
+    } else {
+        p = c.post ? c.post + ((size_t)b * 6 + (qn - 2)) * c.npb : nullptr;
+        n = c.npb;
+    }
+    double s = 0.0;
+    if (p)
+        for (int q = threadIdx.x; q < n; q += 256) s += p[q];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        SalsaScal s;
-        s.resid2 = resid2;
-        s.tv_u = tv;
-        s.mse_num = ps[0];
-        s.dist_num = ps[1];
-        s.x2 = ps[2];
-        s.u2 = ps[3];
-        s.dx2 = ps[4];
-        s.pad = ctrl ? (double)ctrl[b].k : 0.0;   // Chambolle iterations actually run
-        out[b] = s;
+        double *o = reinterpret_cast<double *>(&out[b]);      // SalsaScal is 8 doubles in this order
+        o[qn] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (qn == 0) o[7] = ctrl ? (double)ctrl[b].k : 0.0;   // Chambolle iterations actually run
     }
 }
-
 
 }  // namespace sbtv
 
@@ -75,7 +77,7 @@ void sbtv_salsa_opts_default(sbtv_salsa_opts *o) {
     o->TViters = 5;            // :181
     o->initialization = 0;     // :174
     o->compute_mse = 0;        // :172
-    o->speculate = 0;
+    o->speculate = 1;
     o->tolA = 0.001;           // :178
     o->chambolle_tol = 1e-3;   // chambolle_prox_TV_stop.m:78
     o->chambolle_tau = 0.249;  // chambolle_prox_TV_stop.m:77
@@ -105,18 +107,19 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const int maxiter = opts->maxiter;
     const bool want_mse = (true_x != nullptr);
     const bool crit2 = (opts->stopcriterion == 2);
+    const int lag = opts->speculate ? 1 : 0;
 
     // ---- stage inputs
     const double *yd = nullptr, *td = nullptr, *xi = nullptr;
     SBTV_TRY(stage_in(ctx, "salsa.y", y, cnt, flags, &yd));
     SBTV_TRY(stage_in(ctx, "salsa.true", true_x, cnt, flags, &td));
     SBTV_TRY(stage_in(ctx, "salsa.xinit", x_init, cnt, flags, &xi));
-    double *x = nullptr, *xn = nullptr, *u = nullptr, *bu = nullptr, *g = nullptr;
-    SBTV_TRY(ws_get_t(ctx, "salsa.x", cnt, &x));
+    double *xbuf[2] = {nullptr, nullptr}, *u = nullptr, *bu = nullptr, *g = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.x0", cnt, &xbuf[0]));
+    SBTV_TRY(ws_get_t(ctx, "salsa.x1", cnt, &xbuf[1]));
     SBTV_TRY(ws_get_t(ctx, "salsa.u", cnt, &u));
     SBTV_TRY(ws_get_t(ctx, "salsa.bu", cnt, &bu));
     SBTV_TRY(ws_get_t(ctx, "salsa.g", cnt, &g));
-    if (crit2) SBTV_TRY(ws_get_t(ctx, "salsa.xn", cnt, &xn));
     double2 *S = nullptr, *Hs = nullptr, *Ys = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.S", cnt / 2, &S));
     SBTV_TRY(ws_get_t(ctx, "salsa.H", (size_t)batch * (fp.n1 + 1) * N, &Hs));
@@ -143,14 +146,17 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const int npb = ew_blocks(P);
     double *acc = nullptr, *postp = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.acc", (size_t)batch * 3 * nrb, &acc));
-    SBTV_TRY(ws_get_t(ctx, "salsa.post", (size_t)batch * 5 * npb, &postp));
-    SalsaScal *scal_d = nullptr;
-    SBTV_TRY(ws_get_t(ctx, "salsa.scal", (size_t)batch, &scal_d));
-    SalsaScal *scal_h = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.post", (size_t)batch * 6 * npb, &postp));
+    SalsaScal *scal_d = nullptr;       // [2][batch]
+    SBTV_TRY(ws_get_t(ctx, "salsa.scal", 2 * (size_t)batch, &scal_d));
+    SalsaScal *scal_h = nullptr;       // pinned [2][batch] + frozen staging
+    int *frozen_h = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * batch, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 2 * batch + sizeof(int) * batch, &pz));
         scal_h = static_cast<SalsaScal *>(pz);
+        frozen_h = reinterpret_cast<int *>(scal_h + 2 * (size_t)batch);
+        for (int b = 0; b < batch; ++b) frozen_h[b] = 0;
     }
     const double inv_scale = 1.0 / ((double)fp.n1 * N);
     const double parseval = 1.0 / ((double)M * N);
@@ -169,6 +175,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     ctx->calls += 2LL * batch;                               // AT(y), invLS(ATy) size check (:298)
 
     // ---- initialisation (:366-381)
+    double *x = xbuf[0];
     if (opts->initialization == 0) {
         SBTV_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * cnt, ctx->stream));   // AT(zeros) == 0
         ctx->calls += batch;
@@ -193,9 +200,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
 
     // ---- initial objective (:399-401): resid = y - A(x)
-    double *tvp = nullptr;
-    int ntv = 0;
+    std::vector<double> obj_prev(batch);
     {
+        double *tvp = nullptr;
+        int ntv = 0;
         RowsArgs a{};
         a.dir_fwd = 1;
         a.op = OP_RESID;
@@ -209,7 +217,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
         if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
         Collect c{acc, nrb, tvp, ntv, nullptr, 0};
-        hipLaunchKernelGGL(salsa_collect_kernel, dim3(batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)nullptr, scal_d);
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)nullptr, scal_d);
         SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
         std::vector<double> h4((size_t)batch * 4, 0.0);
         if (want_mse) SBTV_HIP(ctx, hipMemcpyAsync(h4.data(), o4, sizeof(double) * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -217,66 +225,84 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         for (int b = 0; b < batch; ++b) {
             h_numA[b] += 1;
             const double f0 = 0.5 * (scal_h[b].resid2 * parseval) + tau[b] * scal_h[b].tv_u;
+            obj_prev[b] = f0;
             if (objective) objective[(size_t)b * (maxiter + 1)] = f0;
             if (times) times[(size_t)b * (maxiter + 1)] = 0.0;
             if (mses && want_mse) mses[(size_t)b * (maxiter + 1)] = h4[(size_t)b * 4] / (double)P;
         }
         ctx->calls += batch;
     }
-    std::vector<double> obj_prev(batch), obj_cur(batch);
-    for (int b = 0; b < batch; ++b) obj_prev[b] = 0.5 * (scal_h[b].resid2 * parseval) + tau[b] * scal_h[b].tv_u;
 
     std::vector<int> frozen(batch, 0), h_nouter(batch, 0);
     int active = batch;
     double ms_prox = 0.0;
-    long long prox_launches = 0;
+    long long prox_iters_run = 0;
+    hipEvent_t ev_done[2], ev_p0[2], ev_p1[2];
+    for (int s = 0; s < 2; ++s) {
+        SBTV_HIP(ctx, hipEventCreate(&ev_done[s]));
+        SBTV_HIP(ctx, hipEventCreate(&ev_p0[s]));
+        SBTV_HIP(ctx, hipEventCreate(&ev_p1[s]));
+    }
+    auto destroy_events = [&]() {
+        for (int s = 0; s < 2; ++s) {
+            (void)hipEventDestroy(ev_done[s]);
+            (void)hipEventDestroy(ev_p0[s]);
+            (void)hipEventDestroy(ev_p1[s]);
+        }
+    };
     const auto t0 = std::chrono::steady_clock::now();
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
 
-    for (int outer = 1; outer <= maxiter && active > 0; ++outer) {
+    // enqueue outer iteration `outer` (reads x = xbuf[(outer-1)&1] through g, writes xbuf[outer&1])
+    auto enqueue = [&](int outer) -> int {
+        const int slot = outer & 1;
+        double *xn = xbuf[slot];
+        const double *xprev = xbuf[slot ^ 1];
         // (1) TV prox with warm-started duals (:429)
-        if (outer > 1) SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, frozen_d));
-        SBTV_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        if (outer > 1)
+            SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, frozen_d));
+        SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
         SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters));
-        SBTV_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
         SBTV_TRY(prox_finish(ctx, pp, g, u));
-        SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));
         // (2) LS step in the spectral domain + residual energy (:434-444)
-        {
-            RowsArgs a{};
-            a.dir_fwd = 1;
-            a.dir_inv = 1;
-            a.op = OP_SALSA;
-            a.H = Hs;
-            a.Y = Ys;
-            a.mu = mu_d;
-            a.acc = acc;
-            a.frozen = frozen_d;
-            SBTV_TRY(fft_cols_fwd_f(ctx, fp, u, bu, S, frozen_d));
-            SBTV_TRY(fft_rows(ctx, fp, S, S, a));
-            SBTV_TRY(fft_cols_inv_f(ctx, fp, S, crit2 ? xn : x, inv_scale, frozen_d));
-        }
-        // (3) bu update, next prox input, sums (:440-451)
-        SBTV_TRY(salsa_post(ctx, crit2 ? xn : x, x, u, bu, g, td, postp, P, batch, frozen_d, crit2 ? 1 : 0));
-        {
-            Collect c{acc, nrb, tvp, ntv, postp, npb};
-            hipLaunchKernelGGL(salsa_collect_kernel, dim3(batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)pp.ctrl, scal_d);
-        }
-        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        {
-            float ms = 0.f;
-            SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-            ms_prox += ms;
-        }
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.dir_inv = 1;
+        a.op = OP_SALSA;
+        a.H = Hs;
+        a.Y = Ys;
+        a.mu = mu_d;
+        a.acc = acc;
+        a.frozen = frozen_d;
+        SBTV_TRY(fft_cols_fwd_f(ctx, fp, u, bu, S, frozen_d));
+        SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+        SBTV_TRY(fft_cols_inv_f(ctx, fp, S, xn, inv_scale, frozen_d));
+        // (3) bu update, next prox input, sums incl. TVnorm(u) (:440-451)
+        SBTV_TRY(salsa_post(ctx, xn, crit2 ? xprev : nullptr, u, bu, g, td, postp, M, N, batch, frozen_d));
+        Collect c{acc, nrb, nullptr, 0, postp, npb};
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)pp.ctrl,
+                           scal_d + (size_t)slot * batch);
+        SBTV_HIP(ctx, hipMemcpyAsync(scal_h + (size_t)slot * batch, scal_d + (size_t)slot * batch,
+                                     sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipEventRecord(ev_done[slot], ctx->stream));
+        return 0;
+    };
+    // host side of outer iteration `outer`: traces + stopping rule (:444-482)
+    auto process = [&](int outer) -> int {
+        const int slot = outer & 1;
+        SBTV_HIP(ctx, hipEventSynchronize(ev_done[slot]));
+        float ms = 0.f;
+        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ev_p0[slot], ev_p1[slot]));
+        ms_prox += ms;
         const double tnow = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         bool changed = false;
         for (int b = 0; b < batch; ++b) {
             if (frozen[b]) continue;
-            const SalsaScal &s = scal_h[b];
+            const SalsaScal &s = scal_h[(size_t)slot * batch + b];
             h_numA[b] += 1;
             h_nouter[b] = outer;
-            prox_launches += (long long)s.pad;
+            prox_iters_run += (long long)s.pad;
             ctx->calls += 2;   // invLS + A (callcounter)
             const double f = 0.5 * (s.resid2 * parseval) + tau[b] * s.tv_u;                  // :444
             if (objective) objective[(size_t)b * (maxiter + 1) + outer] = f;
@@ -297,12 +323,28 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             obj_prev[b] = f;
             if (stop) {
                 frozen[b] = 1;
+                frozen_h[b] = 1;
                 --active;
                 changed = true;
             }
         }
         if (changed && active > 0)
-            SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen.data(), sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+            SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen_h, sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    };
+
+    int rc = 0, enq = 0, done = 0;
+    while (active > 0 && done < maxiter) {
+        // keep up to 1 + lag iterations in flight
+        while (rc == 0 && enq < maxiter && enq - done <= lag && active > 0) rc = enqueue(++enq);
+        if (rc != 0) break;
+        rc = process(++done);
+        if (rc != 0) break;
+    }
+    if (rc != 0) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_events();
+        return rc;
     }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -311,14 +353,18 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ctx->timing[0] = ms;
         ctx->timing[1] = ms_prox;
-        ctx->timing[2] = (double)prox_launches / batch;      // image-iterations averaged over the batch
-        ctx->timing[3] = 40.0 * (double)P * (double)prox_launches;
+        ctx->timing[2] = (double)prox_iters_run / batch;      // Chambolle iterations (image-averaged)
+        ctx->timing[3] = 40.0 * (double)P * (double)prox_iters_run;
     }
+    destroy_events();
     if (x_out) {
-        if (flags & SBTV_DEVICE_PTRS)
-            SBTV_HIP(ctx, hipMemcpyAsync(x_out, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-        else
-            SBTV_HIP(ctx, hipMemcpyAsync(x_out, x, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        // image b's result is the x written by ITS last processed iteration
+        for (int b = 0; b < batch; ++b) {
+            const double *src = xbuf[h_nouter[b] & 1] + (size_t)b * P;
+            SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, src, sizeof(double) * P,
+                                         (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                         ctx->stream));
+        }
         SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     for (int b = 0; b < batch; ++b) {

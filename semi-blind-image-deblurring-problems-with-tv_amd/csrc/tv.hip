@@ -217,13 +217,14 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
 // identical to one-iteration-at-a-time execution.
 // ---------------------------------------------------------------------------
 constexpr int FH = 6;                    // halo = max fused iterations
+constexpr int FHJ = 5;                   // column halo = max steps per launch (rows need an even halo: FH)
 constexpr int FNW = 4;                   // waves per block
 constexpr int FRI = 128;                 // region rows
 constexpr int FCI = FRI - 2 * FH;        // core rows   (116)
 // columns per wave (CJ) is a tuning parameter: region columns = 4 CJ, core columns = 4 CJ - 2 FH
 struct FusedVariant { int cj; int minw; int fast; };
 static FusedVariant g_fused = {8, 2, 1};
-static inline int fused_core_cols() { return g_fused.cj * FNW - 2 * FH; }
+static inline int fused_core_cols() { return g_fused.cj * FNW - 2 * FHJ; }
 
 __device__ __forceinline__ double dpp_from_prev_lane(double v) {   // lane l gets lane l-1 (lane 0: 0)
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -241,12 +242,11 @@ __device__ __forceinline__ double dpp_from_next_lane(double v) {   // lane l get
 #include "tv_fused.inc"
 
 // Stop rule after a fused launch of `steps_arg` iterations (see the kernel header).
-__global__ __launch_bounds__(256) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
-                                                                    const double *__restrict__ partials, int nblk,
-                                                                    int steps_arg, int redo_mode) {
+__global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
+                                                                       const double *__restrict__ partials, int nblk,
+                                                                       int steps_arg, int redo_mode) {
     const int b = blockIdx.x;
     ProxCtrl *c = &ctrl[b];
-    __shared__ double red[4];
     __shared__ double tots[FH];
     int nsteps;
     if (redo_mode) {
@@ -257,12 +257,25 @@ __global__ __launch_bounds__(256) void chambolle_fused_ctrl_kernel(ProxCtrl *__r
         nsteps = min(steps_arg, c->maxiter - c->k);
         if (nsteps <= 0) return;
     }
-    for (int s = 0; s < nsteps; ++s) {
-        const double *p = partials + ((size_t)b * FH + s) * nblk;
-        double acc = 0.0;
-        for (int q = threadIdx.x; q < nblk; q += 256) acc += p[q];
-        const double tot = block_sum_256(acc, red);
-        if (threadIdx.x == 0) tots[s] = tot;
+    {
+        // wave s sums the partials of step s (fixed order: lane-strided, then the xor tree)
+        const int s = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (s < nsteps) {
+            const double *p = partials + ((size_t)b * FH + s) * nblk;
+            double acc = 0.0;
+            for (int base = 0; base < nblk; base += 64 * 16) {           // 16 independent loads in flight
+                double v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = base + r * 64 + lane;
+                    v[r] = (q < nblk) ? p[q] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc += v[r];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) tots[s] = acc;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -451,7 +464,7 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl) {
             init = true;
             if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,minw"
                 int cj = 0, mw = 0;
-                if (sscanf(e, "%d,%d", &cj, &mw) == 2 && (cj == 8 || cj == 12 || cj == 16) && (mw == 1 || mw == 2)) {
+                if (sscanf(e, "%d,%d", &cj, &mw) == 2 && (cj == 8 || cj == 12 || cj == 16) && (mw >= 1 && mw <= 3)) {
                     g_fused.cj = cj;
                     g_fused.minw = mw;
                 }
@@ -510,8 +523,8 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
     static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
     if (v && !env_single && !g_force_single_step) {
         // temporally fused path: ceil(K/FH) launches of (nearly) equal step counts + the redo pair
-        const dim3 fgrid(pl.ftiles_i, pl.ftiles_j, pl.batch);
-        const int nl = (maxiter + FH - 1) / FH;
+        const dim3 fgrid(pl.fnblk, 1, pl.batch);   // linear tile list, remapped per XCD inside the kernel
+        const int nl = (maxiter + FHJ - 1) / FHJ;
         const int base = maxiter / nl, extra = maxiter % nl;
         auto launch_fused = [&](int steps, int redo) {
 #define SBTV_FUSED_CASE(CJ_, MW_)                                                                                    \
@@ -531,8 +544,9 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED_CASE(8, 1)
             SBTV_FUSED_CASE(12, 1)
             SBTV_FUSED_CASE(16, 1)
+            SBTV_FUSED_CASE(8, 3)
 #undef SBTV_FUSED_CASE
-            hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(256), 0, ctx->stream, pl.ctrl,
+            hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FH), 0, ctx->stream, pl.ctrl,
                                pl.partials, pl.fnblk, steps, redo);
         };
         for (int l = 0; l < nl; ++l) launch_fused(base + (l < extra ? 1 : 0), 0);
