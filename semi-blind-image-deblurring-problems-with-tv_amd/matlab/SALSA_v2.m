@@ -1,0 +1,62 @@
+function [x, numA, numAt, objective, distance, times, mses] = SALSA_v2(y, A, tau, varargin)
+% Drop-in replacement of SALSA/SALSA_v2.m for the TV path of the demos, running device-resident on
+% the MI355X through libsbtv.so.  Same signature and name/value options.
+%
+% The C-ABI needs the operator as PSF taps instead of function handles: pass the 7x7 kernel with the
+% extra option  'PSF', h   (h = Gaussian_psf(...), psf_moffat(...), psf_laplace(...)); the handles given
+% as A / 'AT' / 'LS' are then only checked for presence, exactly like the reference checks them, and
+% 'MU' must be the mu that 'LS' was built with (run_Gaussian_demo.m:222-225).
+persistent ctx
+if isempty(ctx), ctx = sbtv_load(0); end
+stopCriterion = 1; maxiter = 10000; init = 0; AT = 0; mu = 1e-3; tolA = 0.001;
+isTVinitialization = 0; TViters = 5; verbose = 1; isinvLS = 0; compute_mse = 0; h = []; true_x = []; xinit = [];
+if (rem(length(varargin),2)==1)
+    error('Optional parameters should always go by pairs');
+end
+for i = 1:2:(length(varargin)-1)
+    switch upper(varargin{i})
+        case 'PSF',              h = varargin{i+1};
+        case {'PSI','PHI','P','PT'}   % accepted and ignored on the TV path (SALSA_v2.m:318-320)
+        case 'TVINITIALIZATION', isTVinitialization = varargin{i+1};
+        case 'TVITERS',          TViters = varargin{i+1};
+        case 'MU',               mu = varargin{i+1};
+        case 'STOPCRITERION',    stopCriterion = varargin{i+1};
+        case 'TOLERANCEA',       tolA = varargin{i+1};
+        case 'MAXITERA',         maxiter = varargin{i+1};
+        case 'INITIALIZATION'
+            if numel(varargin{i+1}) > 1, init = 33333; xinit = varargin{i+1}; else, init = varargin{i+1}; end
+        case 'TRUE_X',           compute_mse = 1; true_x = varargin{i+1};
+        case 'AT',               AT = varargin{i+1};
+        case 'VERBOSE',          verbose = varargin{i+1};
+        case 'LS',               isinvLS = 1;
+        otherwise
+            error(['Unrecognized option: ''' varargin{i} '''']);
+    end
+end
+if (sum(stopCriterion == [1 2 3])==0), error('Unknown stopping criterion'); end
+if isa(A, 'function_handle') && ~isa(AT,'function_handle')
+    error('The function handle for transpose of A is missing');
+end
+if ~isinvLS, error('(A^T A + \mu I)^(-1) must be specified as a function handle.\n'); end
+if isempty(h), error('sbtv:SALSA_v2', 'pass the PSF taps with the option ''PSF'''); end
+if ~isTVinitialization, error('sbtv:SALSA_v2', 'only ''TVINITIALIZATION'',1 runs on the GPU path'); end
+[M, N] = size(y);
+o = libstruct('sbtv_salsa_opts');
+calllib('libsbtv', 'sbtv_salsa_opts_default', o);
+o.stopcriterion = stopCriterion; o.maxiter = maxiter; o.TViters = TViters; o.initialization = init;
+o.compute_mse = compute_mse; o.tolA = tolA;
+px = libpointer('doublePtr', zeros(M,N));
+pobj = libpointer('doublePtr', zeros(1,maxiter+1)); pdist = libpointer('doublePtr', zeros(1,maxiter));
+ptim = libpointer('doublePtr', zeros(1,maxiter+1)); pmse = libpointer('doublePtr', zeros(1,maxiter+1));
+pnA = libpointer('int32Ptr', int32(0)); pnAt = libpointer('int32Ptr', int32(0)); pn = libpointer('int32Ptr', int32(0));
+rc = calllib('libsbtv', 'sbtv_SALSA_v2', ctx, y, int32(M), int32(N), int32(1), h, int32(size(h,1)), tau, mu, o, ...
+             true_x, xinit, px, pobj, pdist, ptim, pmse, pnA, pnAt, pn, int32(0));
+if rc ~= 0, error('sbtv:SALSA_v2', '%s', calllib('libsbtv', 'sbtv_last_error', ctx)); end
+k = double(pn.Value);
+x = reshape(px.Value, M, N); numA = double(pnA.Value); numAt = double(pnAt.Value);
+objective = pobj.Value(1:k+1); distance = pdist.Value(1:k); times = ptim.Value(1:k+1);
+if compute_mse, mses = pmse.Value(1:k+1); else, mses = []; end
+if verbose
+    fprintf('\niter = %d, obj = %3.3g\n', k, objective(end));
+end
+end
