@@ -262,9 +262,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         if (outer > 1)
             SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, frozen_d));
         SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
-        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters));
+        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u));     // u = g - lambda div p written by the last launch
         SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
-        SBTV_TRY(prox_finish(ctx, pp, g, u));
         // (2) LS step in the spectral domain + residual energy (:434-444)
         RowsArgs a{};
         a.dir_fwd = 1;

@@ -271,8 +271,7 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
         SBTV_TRY(prox_zero_duals(ctx, pp));
         SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
-        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters));
-        SBTV_TRY(prox_finish(ctx, pp, y, x));
+        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x));
         t = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                     // :28
         {
             std::vector<double> coef(batch, (t_old - 1) / t);            // :29
@@ -471,8 +470,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     auto do_prox = [&]() -> int {   // prox = chambolle(X, lambda*theta, cold start)
         SBTV_TRY(prox_zero_duals(ctx, pp));
         SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
-        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit));
-        SBTV_TRY(prox_finish(ctx, pp, X, prox));
+        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox));
         return 0;
     };
 

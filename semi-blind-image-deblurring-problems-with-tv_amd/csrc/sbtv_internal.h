@@ -21,7 +21,7 @@ struct ProxCtrl {
     int cur;       // which dual ping-pong buffer holds the current (px,py)
     int maxiter;
     int redo;      // >0: the last fused launch over-ran the stop rule; re-run that many steps from `cur`
-    int pad;
+    int f_valid;   // 1: a fused launch already stored the final f = g - lambda div p
     double err;    // last err (chambolle_prox_TV_stop.m:128)
     double lambda;
     double tol;
@@ -121,7 +121,8 @@ int prox_zero_duals(sbtv_ctx *ctx, const ProxPlan &pl);
 int prox_set_duals(sbtv_ctx *ctx, const ProxPlan &pl, const double *px, const double *py);   // device ptrs
 int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);               // device ptrs
 // Run up to `maxiter` iterations (device-side early exit), no host sync.
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter);
+// If f_out is given it receives f = g - lambda div p (fused into the last launch where possible).
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr);
 // f = g - lambda * div(p)
 int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
 // periodic TV norm of x -> out_dev[batch] (device)

@@ -217,14 +217,16 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
 // identical to one-iteration-at-a-time execution.
 // ---------------------------------------------------------------------------
 constexpr int FH = 6;                    // halo = max fused iterations
-constexpr int FHJ = 5;                   // column halo = max steps per launch (rows need an even halo: FH)
-constexpr int FNW = 4;                   // waves per block
+constexpr int FHJ = 5;                   // right column halo = max steps per launch (rows need an even halo: FH)
+constexpr int FHL = FHJ + 1;             // left column halo: one more, because f = g - lambda div p written by the
+                                         // last launch needs py(i, j-1) of the FINAL iterate left of the core
 constexpr int FRI = 128;                 // region rows
 constexpr int FCI = FRI - 2 * FH;        // core rows   (116)
-// columns per wave (CJ) is a tuning parameter: region columns = 4 CJ, core columns = 4 CJ - 2 FH
-struct FusedVariant { int cj; int minw; int fast; };
-static FusedVariant g_fused = {8, 2, 1};
-static inline int fused_core_cols() { return g_fused.cj * FNW - 2 * FHJ; }
+// tuning parameters: columns per wave (cj) and waves per block (nw): region columns = nw*cj,
+// core columns = nw*cj - 2 FHJ; minw = waves per SIMD requested from the register allocator
+struct FusedVariant { int cj; int nw; int minw; int fast; };
+static FusedVariant g_fused = {4, 8, 4, 1};
+static inline int fused_core_cols() { return g_fused.cj * g_fused.nw - FHL - FHJ; }
 
 __device__ __forceinline__ double dpp_from_prev_lane(double v) {   // lane l gets lane l-1 (lane 0: 0)
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -244,13 +246,16 @@ __device__ __forceinline__ double dpp_from_next_lane(double v) {   // lane l get
 // Stop rule after a fused launch of `steps_arg` iterations (see the kernel header).
 __global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
                                                                        const double *__restrict__ partials, int nblk,
-                                                                       int steps_arg, int redo_mode) {
+                                                                       int steps_arg, int redo_mode, int write_f) {
     const int b = blockIdx.x;
     ProxCtrl *c = &ctrl[b];
     __shared__ double tots[FH];
     int nsteps;
     if (redo_mode) {
-        if (c->redo <= 0) return;
+        if (c->redo <= 0) {
+            if (threadIdx.x == 0 && write_f) c->f_valid = 1;   // the redo launch ran as a finish-only pass (or f was valid)
+            return;
+        }
         nsteps = c->redo;
     } else {
         if (c->done) return;
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl 
             c->err = sqrt(tots[nsteps - 1]);
             c->cur ^= 1;
             c->redo = 0;
+            if (write_f) c->f_valid = 1;
             return;
         }
         for (int s = 0; s < nsteps; ++s) {
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl 
                     c->k = k;
                     c->err = err;
                     c->cur ^= 1;
+                    if (write_f) c->f_valid = 1;   // this launch's f is the final one
                 } else {
                     c->redo = s + 1;       // over-ran: p in the output buffer is too far; re-run s+1 steps
                 }
@@ -305,6 +312,8 @@ __global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl 
         c->k += nsteps;
         c->err = sqrt(tots[nsteps - 1]);
         c->cur ^= 1;
+        // (cannot happen for the last planned launch: k == maxiter always stops; kept for safety)
+        if (write_f && c->k >= c->maxiter) c->f_valid = 1;
     }
 }
 
@@ -341,7 +350,7 @@ __global__ void prox_reset_kernel(ProxCtrl *__restrict__ ctrl, const double *__r
     if (!keep_cur) c.cur = 0;
     c.maxiter = maxiter;
     c.redo = 0;
-    c.pad = 0;
+    c.f_valid = 0;
     c.err = 0.0;
     c.lambda = lambda[b] * lambda_scale;
     c.tol = tol;
@@ -462,10 +471,17 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl) {
         static bool init = false;
         if (!init) {
             init = true;
-            if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,minw"
-                int cj = 0, mw = 0;
-                if (sscanf(e, "%d,%d", &cj, &mw) == 2 && (cj == 8 || cj == 12 || cj == 16) && (mw >= 1 && mw <= 3)) {
+            if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,nw,minw"
+                int cj = 0, nw = 0, mw = 0;
+                static const int known[][3] = {{8, 4, 2}, {8, 8, 2}, {8, 8, 1}, {12, 4, 2}, {16, 4, 1}, {4, 8, 2},
+                                               {4, 16, 2}, {8, 6, 2}, {4, 8, 3}, {4, 8, 4}, {6, 8, 4}, {6, 8, 2},
+                                               {5, 8, 4}};
+                bool ok = false;
+                if (sscanf(e, "%d,%d,%d", &cj, &nw, &mw) == 3)
+                    for (auto &k3 : known) ok = ok || (k3[0] == cj && k3[1] == nw && k3[2] == mw);
+                if (ok) {
                     g_fused.cj = cj;
+                    g_fused.nw = nw;
                     g_fused.minw = mw;
                 }
             }
@@ -517,40 +533,52 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py) {
 
 int g_force_single_step = 0;   // test hook (SBTV_SINGLE_STEP=1): one-iteration kernels only
 
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter) {
+int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
+
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out) {
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
     const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
     static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
-    if (v && !env_single && !g_force_single_step) {
+    if (v && !env_single && !g_force_single_step && (!f_out || vec_ok(f_out, pl.M))) {
         // temporally fused path: ceil(K/FH) launches of (nearly) equal step counts + the redo pair
         const dim3 fgrid(pl.fnblk, 1, pl.batch);   // linear tile list, remapped per XCD inside the kernel
         const int nl = (maxiter + FHJ - 1) / FHJ;
         const int base = maxiter / nl, extra = maxiter % nl;
-        auto launch_fused = [&](int steps, int redo) {
-#define SBTV_FUSED_CASE(CJ_, MW_)                                                                                    \
-    if (g_fused.cj == CJ_ && g_fused.minw == MW_) {                                                                  \
+        auto launch_fused = [&](int steps, int redo, int write_f) {
+            bool launched = false;
+#define SBTV_FUSED_CASE(CJ_, NW_, MW_)                                                                               \
+    if (g_fused.cj == CJ_ && g_fused.nw == NW_ && g_fused.minw == MW_) {                                             \
+        launched = true;                                                                                             \
         if (g_fused.fast)                                                                                            \
-            hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, MW_, true>), fgrid, dim3(64 * FNW), 0, ctx->stream, g,   \
-                               pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps,    \
-                               redo);                                                                                \
+            hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
+                               g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
+                               redo, f_out, write_f);                                                                \
         else                                                                                                         \
-            hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, MW_, false>), fgrid, dim3(64 * FNW), 0, ctx->stream, g,  \
-                               pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps,    \
-                               redo);                                                                                \
+            hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
+                               ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
+                               pl.fnblk, steps, redo, f_out, write_f);                                               \
     }
-            SBTV_FUSED_CASE(8, 2)
-            SBTV_FUSED_CASE(12, 2)
-            SBTV_FUSED_CASE(16, 2)
-            SBTV_FUSED_CASE(8, 1)
-            SBTV_FUSED_CASE(12, 1)
-            SBTV_FUSED_CASE(16, 1)
-            SBTV_FUSED_CASE(8, 3)
+            SBTV_FUSED_CASE(8, 4, 2)
+            SBTV_FUSED_CASE(8, 8, 2)
+            SBTV_FUSED_CASE(8, 8, 1)
+            SBTV_FUSED_CASE(12, 4, 2)
+            SBTV_FUSED_CASE(16, 4, 1)
+            SBTV_FUSED_CASE(4, 8, 2)
+            SBTV_FUSED_CASE(4, 16, 2)
+            SBTV_FUSED_CASE(8, 6, 2)
+            SBTV_FUSED_CASE(4, 8, 3)
+            SBTV_FUSED_CASE(4, 8, 4)
+            SBTV_FUSED_CASE(6, 8, 4)
+            SBTV_FUSED_CASE(6, 8, 2)
+            SBTV_FUSED_CASE(5, 8, 4)
 #undef SBTV_FUSED_CASE
+            (void)launched;
             hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FH), 0, ctx->stream, pl.ctrl,
-                               pl.partials, pl.fnblk, steps, redo);
+                               pl.partials, pl.fnblk, steps, redo, write_f);
         };
-        for (int l = 0; l < nl; ++l) launch_fused(base + (l < extra ? 1 : 0), 0);
-        launch_fused(0, 1);
+        const int wf = f_out ? 1 : 0;
+        for (int l = 0; l < nl; ++l) launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0);
+        launch_fused(0, 1, wf);     // redo pass; doubles as the finish-only pass when f is not valid yet
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
@@ -565,6 +593,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                            pl.nblk);
     }
     SBTV_HIP(ctx, hipGetLastError());
+    if (f_out) return prox_finish(ctx, pl, g, f_out);
     return 0;
 }
 
@@ -645,13 +674,10 @@ int sbtv_chambolle_prox_TV_stop(sbtv_ctx *ctx, const double *g, int M, int N, in
     } else {
         SBTV_TRY(prox_zero_duals(ctx, pl));
     }
-    SBTV_TRY(prox_iterate(ctx, pl, gd, maxiter));
     double *fd = nullptr, *pxo = nullptr, *pyo = nullptr;
-    if (f) {
-        SBTV_TRY(stage_out_buf(ctx, "prox.out.f", f, cnt, flags, &fd));
-        SBTV_TRY(prox_finish(ctx, pl, gd, fd));
-        SBTV_TRY(stage_out_copy(ctx, f, fd, cnt, flags));
-    }
+    if (f) SBTV_TRY(stage_out_buf(ctx, "prox.out.f", f, cnt, flags, &fd));
+    SBTV_TRY(prox_iterate(ctx, pl, gd, maxiter, fd));
+    if (f) SBTV_TRY(stage_out_copy(ctx, f, fd, cnt, flags));
     if (px && py) {
         SBTV_TRY(stage_out_buf(ctx, "prox.out.px", px, cnt, flags, &pxo));
         SBTV_TRY(stage_out_buf(ctx, "prox.out.py", py, cnt, flags, &pyo));
