@@ -591,7 +591,16 @@ int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, 
     return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
 }
 
-static inline int rows_rk(int N) { return (N >= 512) ? 4 : 8; }
+// rows per workgroup of the row pass: 4 (64-byte segments) from N = 512 on, 8 below; N = 2048 may use
+// 2 (SBTV_ROWS_RK=2: 512-thread workgroups, two per CU so load / FFT / store phases overlap)
+static inline int rows_rk(int N) {
+    static const int rk2048 = [] {
+        const char *e = getenv("SBTV_ROWS_RK");
+        return (e && atoi(e) == 2) ? 2 : 4;
+    }();
+    if (N == 2048) return rk2048;
+    return (N >= 512) ? 4 : 8;
+}
 int fft_rows_blocks(const FftPlan &pl) { return pl.n1 / rows_rk(pl.N); }
 
 template <int L, int RK>
@@ -634,7 +643,10 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
         switch (L) {
             case 9: launch_rows<9, 4>(ctx, pl, p); break;
             case 10: launch_rows<10, 4>(ctx, pl, p); break;
-            case 11: launch_rows<11, 4>(ctx, pl, p); break;
+            case 11:
+                if (rows_rk(pl.N) == 2) launch_rows<11, 2>(ctx, pl, p);
+                else launch_rows<11, 4>(ctx, pl, p);
+                break;
             default: break;
         }
     } else {

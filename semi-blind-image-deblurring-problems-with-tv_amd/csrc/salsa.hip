@@ -150,11 +150,15 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     SalsaScal *scal_d = nullptr;       // [2][batch]
     SBTV_TRY(ws_get_t(ctx, "salsa.scal", 2 * (size_t)batch, &scal_d));
     SalsaScal *scal_h = nullptr;       // pinned [2][batch] + frozen staging
+    SalsaScal *scal_hd = nullptr;      // the same pinned block as seen from the device
     int *frozen_h = nullptr;
     {
         void *pz = nullptr;
         SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 2 * batch + sizeof(int) * batch, &pz));
         scal_h = static_cast<SalsaScal *>(pz);
+        void *dp = nullptr;
+        SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
+        scal_hd = static_cast<SalsaScal *>(dp);
         frozen_h = reinterpret_cast<int *>(scal_h + 2 * (size_t)batch);
         for (int b = 0; b < batch; ++b) frozen_h[b] = 0;
     }
@@ -280,10 +284,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         // (3) bu update, next prox input, sums incl. TVnorm(u) (:440-451)
         SBTV_TRY(salsa_post(ctx, xn, crit2 ? xprev : nullptr, u, bu, g, td, postp, M, N, batch, frozen_d));
         Collect c{acc, nrb, nullptr, 0, postp, npb};
+        // the collector writes the eight scalars straight into pinned host memory (no copy kernel);
+        // they are visible to the host once ev_done has completed
         hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)pp.ctrl,
-                           scal_d + (size_t)slot * batch);
-        SBTV_HIP(ctx, hipMemcpyAsync(scal_h + (size_t)slot * batch, scal_d + (size_t)slot * batch,
-                                     sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
+                           scal_hd + (size_t)slot * batch);
         SBTV_HIP(ctx, hipEventRecord(ev_done[slot], ctx->stream));
         return 0;
     };
