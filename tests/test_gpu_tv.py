@@ -88,6 +88,37 @@ def test_prox_early_exit_and_structure(ctx):
     assert not px[-1, :].any() and not py[:, -1].any() and f[-1, -1] == g[-1, -1]
 
 
+@pytest.mark.parametrize("kstop", [2, 4, 5, 6, 8, 10, 13])
+def test_prox_tolerance_stop_inside_and_between_fused_launches(ctx, kstop):
+    """The stop rule (:131) firing in the middle of a fused 5-iteration launch (redo pass), exactly at a
+    launch boundary (finish-only pass) and in a later launch must give the reference's k, err, p and f."""
+    import sbtv
+    import sbtv_oracle as o
+    g = synth_image(96, 80, 21) + np.random.default_rng(3).standard_normal((96, 80))
+    lam, K = 8.0, 15
+    errs = []
+    for k in range(1, K + 1):
+        errs.append(o.chambolle_prox_TV_stop(g, lam=lam, maxiter=k, return_info=True)[4])
+    assert all(a > b for a, b in zip(errs, errs[1:])), "test assumes a decreasing err sequence"
+    tol = 0.5 * (errs[kstop - 1] + errs[kstop - 2])        # err_{kstop-1} > tol > err_kstop
+    fo, pxo, pyo, ko, erro = o.chambolle_prox_TV_stop(g, lam=lam, maxiter=K, tol=tol, return_info=True)
+    assert ko == kstop
+    f, px, py, k, err = sbtv.chambolle_prox_TV_stop(g, "lambda", lam, "maxiter", K, "tol", tol, return_info=True)
+    assert k[0] == kstop and err[0] == pytest.approx(erro, rel=1e-12)
+    np.testing.assert_allclose(px, pxo, **TOL)
+    np.testing.assert_allclose(py, pyo, **TOL)
+    np.testing.assert_allclose(f, fo, rtol=1e-12, atol=1e-10)
+    # batch: image 0 stops at kstop, image 1 (other lambda => other errs) runs its own course
+    g2 = np.stack([g, g[::-1].copy()])
+    f2, px2, py2, k2, err2 = sbtv.chambolle_prox_TV_stop(g2, "lambda", [lam, 3.0], "maxiter", K, "tol", tol,
+                                                        return_info=True)
+    fo1, pxo1, pyo1, ko1, erro1 = o.chambolle_prox_TV_stop(g2[1], lam=3.0, maxiter=K, tol=tol, return_info=True)
+    assert list(k2) == [kstop, ko1]
+    np.testing.assert_allclose(f2[0], fo, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(f2[1], fo1, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(px2[1], pxo1, **TOL)
+
+
 def test_prox_errors(ctx):
     import sbtv
     g = np.zeros((8, 8))
