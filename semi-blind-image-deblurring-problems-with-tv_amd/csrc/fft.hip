@@ -127,13 +127,15 @@ __device__ __forceinline__ void apply_twiddles(double2 (&v)[8], int t, const dou
 // LDS exchange accessors ------------------------------------------------------
 // Column kernels: each sequence has its own padded region, t is the fast lane index.
 struct ColsX {
-    double *lds;     // base of this sequence's region
+    double *lds;     // base of this sequence's region (real plane)
+    int im_off;      // offset (in doubles) of the imaginary plane; 0 = one plane used for re and im in turn
     __device__ __forceinline__ int idx(int pos) const { return pos + (pos >> 3); }
 };
 // Row kernels: RK sequences interleaved (sequence index fastest).
 template <int RK>
 struct RowsX {
     double *lds;
+    int im_off;
     int q;
     __device__ __forceinline__ int idx(int pos) const {
         const int i = pos * RK + q;
@@ -155,6 +157,23 @@ __device__ __forceinline__ void exchange(double2 (&v)[8], int t, const X &x) {
 #pragma unroll
         for (int r = 0; r < R; ++r) pos[q + r * G] = x.idx(j0 + (r << LOG2NS));
     }
+    if (x.im_off) {
+        // both planes resident: one write phase, one read phase (2 barriers)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            x.lds[pos[s]] = v[s].x;
+            x.lds[pos[s] + x.im_off] = v[s].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = x.idx(t + s * T);
+            v[s].x = x.lds[i];
+            v[s].y = x.lds[i + x.im_off];
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) x.lds[pos[s]] = v[s].x;
     __syncthreads();
@@ -173,6 +192,23 @@ __device__ __forceinline__ void exchange(double2 (&v)[8], int t, const X &x) {
 template <int LOG2N, class X>
 __device__ __forceinline__ void mirror(const double2 (&v)[8], double2 (&m)[8], int t, const X &x) {
     constexpr int n = 1 << LOG2N, T = n / 8;
+    if (x.im_off) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = x.idx(t + s * T);
+            x.lds[i] = v[s].x;
+            x.lds[i + x.im_off] = v[s].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = x.idx((n - (t + s * T)) & (n - 1));
+            m[s].x = x.lds[i];
+            m[s].y = x.lds[i + x.im_off];
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) x.lds[x.idx(t + s * T)] = v[s].x;
     __syncthreads();
@@ -216,7 +252,7 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_fwd_kernel(const double
     constexpr int n = 1 << LOG2N, T = n / 8;
     constexpr int LDSN = n + (n >> 3);
     constexpr int MAXSEQ = (COLS_THREADS / T) > 0 ? (COLS_THREADS / T) : 1;
-    __shared__ double lds[MAXSEQ * LDSN];
+    __shared__ double lds[2 * MAXSEQ * LDSN];
     const int b = blockIdx.y;
     if (frozen && frozen[b]) return;
     const int nseq = blockDim.x / T;
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_fwd_kernel(const double
     const int j = blockIdx.x * nseq + seq;          // column (grid is exact: N % nseq == 0)
     const size_t colbase = ((size_t)b * N + j) * n;  // in complex elements
     const double2 *__restrict__ xin = reinterpret_cast<const double2 *>(x) + colbase;
-    ColsX X{lds + seq * LDSN};
+    ColsX X{lds + seq * LDSN, MAXSEQ * LDSN};
     double2 v[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = xin[t + s * T];
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double
     constexpr int n = 1 << LOG2N, T = n / 8;
     constexpr int LDSN = n + (n >> 3);
     constexpr int MAXSEQ = (COLS_THREADS / T) > 0 ? (COLS_THREADS / T) : 1;
-    __shared__ double lds[MAXSEQ * LDSN];
+    __shared__ double lds[2 * MAXSEQ * LDSN];
     const int b = blockIdx.y;
     if (frozen && frozen[b]) return;
     const int nseq = blockDim.x / T;
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double
     const int j = blockIdx.x * nseq + seq;
     const size_t colbase = ((size_t)b * N + j) * n;
     const double2 *__restrict__ in = S + colbase;
-    ColsX X{lds + seq * LDSN};
+    ColsX X{lds + seq * LDSN, MAXSEQ * LDSN};
     double2 v[8], m[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = in[t + s * T];
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     constexpr int N = 1 << LOG2N, T = N / 8;
     constexpr int LDSI = RK * N;
     constexpr int LDSN = LDSI + ((LDSI >> 5) << 2) + 8;
-    __shared__ double lds[LDSN];
+    __shared__ double lds[2 * LDSN];
     __shared__ double red[3 * 16];
     const int b = blockIdx.y;
     if (p.frozen && p.frozen[b]) return;
@@ -375,7 +411,7 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     const int n1 = p.n1;
     const size_t ibase = (size_t)b * n1 * N;
     const double2 *__restrict__ in = p.Sin + ibase;
-    RowsX<RK> X{lds, q};
+    RowsX<RK> X{lds, LDSN, q};
     double2 v[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = in[(size_t)(t + s * T) * n1 + k];
