@@ -30,8 +30,12 @@ struct Collect {
 };
 
 // grid (7, batch): block q reduces ONE quantity of SalsaScal (fixed order, deterministic)
-__global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, const ProxCtrl *__restrict__ ctrl,
-                                                             SalsaScal *__restrict__ out) {
+// With rearm = 1 the block that reads the prox control block also re-arms it for the NEXT outer
+// iteration's warm-started prox (k = 0, done = frozen flag, redo = 0, f_valid = 0; lambda / tol /
+// tau / maxiter / cur stay), which saves a separate reset launch per outer iteration.
+__global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl *__restrict__ ctrl,
+                                                             SalsaScal *__restrict__ out,
+                                                             const int *__restrict__ frozen, int rearm) {
     __shared__ double red[4];
     const int b = blockIdx.y, qn = blockIdx.x;
     const double *p = nullptr;
@@ -60,7 +64,18 @@ __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, const Pro
     if (threadIdx.x == 0) {
         double *o = reinterpret_cast<double *>(&out[b]);      // SalsaScal is 8 doubles in this order
         o[qn] = (red[0] + red[1]) + (red[2] + red[3]);
-        if (qn == 0) o[7] = ctrl ? (double)ctrl[b].k : 0.0;   // Chambolle iterations actually run
+        if (qn == 0) {
+            o[7] = ctrl ? (double)ctrl[b].k : 0.0;            // Chambolle iterations actually run
+            if (ctrl && rearm) {
+                ProxCtrl pc = ctrl[b];
+                pc.k = 0;
+                pc.done = (frozen && frozen[b]) ? 1 : 0;
+                pc.redo = 0;
+                pc.f_valid = 0;
+                pc.err = 0.0;
+                ctrl[b] = pc;
+            }
+        }
     }
 }
 
@@ -221,7 +236,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
         if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
         Collect c{acc, nrb, tvp, ntv, nullptr, 0};
-        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)nullptr, scal_d);
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (ProxCtrl *)nullptr, scal_d,
+                           (const int *)nullptr, 0);
         SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
         std::vector<double> h4((size_t)batch * 4, 0.0);
         if (want_mse) SBTV_HIP(ctx, hipMemcpyAsync(h4.data(), o4, sizeof(double) * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -262,9 +278,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         const int slot = outer & 1;
         double *xn = xbuf[slot];
         const double *xprev = xbuf[slot ^ 1];
-        // (1) TV prox with warm-started duals (:429)
-        if (outer > 1)
-            SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, frozen_d));
+        // (1) TV prox with warm-started duals (:429); the control block was re-armed by the previous
+        //     iteration's collector (or by prox_reset before the loop)
         SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
         SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u));     // u = g - lambda div p written by the last launch
         SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
@@ -286,8 +301,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         Collect c{acc, nrb, nullptr, 0, postp, npb};
         // the collector writes the eight scalars straight into pinned host memory (no copy kernel);
         // they are visible to the host once ev_done has completed
-        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (const ProxCtrl *)pp.ctrl,
-                           scal_hd + (size_t)slot * batch);
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, pp.ctrl,
+                           scal_hd + (size_t)slot * batch, (const int *)frozen_d, 1);
         SBTV_HIP(ctx, hipEventRecord(ev_done[slot], ctx->stream));
         return 0;
     };

@@ -110,6 +110,7 @@ struct ProxPlan {
     ProxCtrl *ctrl;               // [batch]
     double *pbuf;                 // [2 pingpong][2 (px,py)][batch][M*N]
     double *partials;             // [batch][nblk]
+    unsigned *counters;           // [batch] arrival tickets (in-kernel stop-rule path)
 };
 int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan);
 // (Re)initialise the control blocks: k=0, done=0 and the per-image lambda from a
