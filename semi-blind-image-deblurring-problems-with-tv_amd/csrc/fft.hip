@@ -291,13 +291,17 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_fwd_kernel(const double
     }
 }
 
-// column pass, inverse: packed half spectrum -> real columns (times `scale`)
-template <int LOG2N>
+// column pass, inverse: packed half spectrum -> real columns (times `scale`).
+// POST = true additionally runs the SALSA bookkeeping pass on the column while x is still in
+// registers (SALSA_v2.m:440-451): bu += u - x ; g = x - bu ; partial sums of (x-true)^2, (x-u)^2,
+// x^2, u^2, (x-xprev)^2 and the periodic TV of u -> post.partials[b][6][gridDim.x].
+template <int LOG2N, bool POST>
 __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double2 *__restrict__ S,
                                                                      double *__restrict__ x,
                                                                      const double2 *__restrict__ tw_n1,
                                                                      const double2 *__restrict__ tw_M, int N,
-                                                                     double scale, const int *__restrict__ frozen) {
+                                                                     double scale, const int *__restrict__ frozen,
+                                                                     ColsPost post) {
     constexpr int n = 1 << LOG2N, T = n / 8;
     constexpr int LDSN = n + (n >> 3);
     constexpr int MAXSEQ = (COLS_THREADS / T) > 0 ? (COLS_THREADS / T) : 1;
@@ -329,8 +333,62 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double
     }
     fft_stages<LOG2N, 0, true>(v, t, tw_n1, X);
     double2 *__restrict__ out = reinterpret_cast<double2 *>(x) + colbase;
+    if constexpr (!POST) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) out[t + s * T] = cscale(v[s], scale);
+        for (int s = 0; s < 8; ++s) out[t + s * T] = cscale(v[s], scale);
+    } else {
+        constexpr int M = 2 * n;
+        const size_t ibase = (size_t)b * N * M;               // image offset in doubles
+        const size_t cb = ibase + (size_t)j * M;              // column offset
+        const size_t cl = ibase + (size_t)(j > 0 ? j - 1 : N - 1) * M;   // periodic left neighbour column
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int e = t + s * T;
+            const size_t o = cb + 2 * (size_t)e;
+            const double2 xv = cscale(v[s], scale);
+            out[e] = xv;
+            const double2 uv = *reinterpret_cast<const double2 *>(post.u + o);
+            double2 bv = *reinterpret_cast<const double2 *>(post.bu + o);
+            bv.x = bv.x + (uv.x - xv.x);
+            bv.y = bv.y + (uv.y - xv.y);
+            *reinterpret_cast<double2 *>(post.bu + o) = bv;
+            *reinterpret_cast<double2 *>(post.g + o) = make_double2(xv.x - bv.x, xv.y - bv.y);
+            if (post.tru) {
+                const double2 tv = *reinterpret_cast<const double2 *>(post.tru + o);
+                const double e0 = xv.x - tv.x, e1 = xv.y - tv.y;
+                acc[0] += e0 * e0 + e1 * e1;
+            }
+            const double d0 = xv.x - uv.x, d1 = xv.y - uv.y;
+            acc[1] += d0 * d0 + d1 * d1;
+            acc[2] += xv.x * xv.x + xv.y * xv.y;
+            acc[3] += uv.x * uv.x + uv.y * uv.y;
+            if (post.xprev) {
+                const double2 xo = *reinterpret_cast<const double2 *>(post.xprev + o);
+                const double p0 = xv.x - xo.x, p1 = xv.y - xo.y;
+                acc[4] += p0 * p0 + p1 * p1;
+            }
+            // periodic isotropic TV of u (utils/TVnorm.m:2)
+            const double up = post.u[e > 0 ? o - 1 : cb + M - 1];
+            const double2 ul = *reinterpret_cast<const double2 *>(post.u + cl + 2 * (size_t)e);
+            const double h0 = uv.x - ul.x, v0 = uv.x - up, h1 = uv.y - ul.y, v1 = uv.y - uv.x;
+            acc[5] += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
+        }
+        // fixed-order block reduction through LDS (the exchange planes are idle now)
+        __syncthreads();
+        const int nthr = blockDim.x;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) lds[c * nthr + threadIdx.x] = acc[c];
+        __syncthreads();
+        for (int stride = nthr >> 1; stride > 0; stride >>= 1) {
+            if ((int)threadIdx.x < stride) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) lds[c * nthr + threadIdx.x] += lds[c * nthr + threadIdx.x + stride];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 6) post.partials[((size_t)b * 6 + threadIdx.x) * gridDim.x + blockIdx.x] = lds[threadIdx.x * nthr];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -584,8 +642,15 @@ template <int L>
 static void launch_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale,
                             const int *frozen) {
     const int nseq = cols_nseq(pl.n1, pl.N);
-    hipLaunchKernelGGL(fft_cols_inv_kernel<L>, dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0, ctx->stream,
-                       S, x, pl.tw_n1, pl.tw_M, pl.N, scale, frozen);
+    hipLaunchKernelGGL((fft_cols_inv_kernel<L, false>), dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0,
+                       ctx->stream, S, x, pl.tw_n1, pl.tw_M, pl.N, scale, frozen, ColsPost{});
+}
+template <int L>
+static void launch_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale,
+                                 const int *frozen, const ColsPost &post) {
+    const int nseq = cols_nseq(pl.n1, pl.N);
+    hipLaunchKernelGGL((fft_cols_inv_kernel<L, true>), dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0,
+                       ctx->stream, S, x, pl.tw_n1, pl.tw_M, pl.N, scale, frozen, post);
 }
 
 #define SBTV_DISPATCH_LOG2(L, CALL)                                    \
@@ -625,6 +690,16 @@ int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x
 }
 int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale) {
     return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
+}
+int fft_cols_blocks(const FftPlan &pl) { return pl.N / cols_nseq(pl.n1, pl.N); }
+int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
+                      const ColsPost &post) {
+    const int L = ilog2(pl.n1);
+#define CALL(LL) launch_cols_inv_post<LL>(ctx, pl, S, x, scale, frozen, post)
+    SBTV_DISPATCH_LOG2(L, CALL)
+#undef CALL
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 // rows per workgroup of the row pass: 4 (64-byte segments) from N = 512 on, 8 below; N = 2048 may use

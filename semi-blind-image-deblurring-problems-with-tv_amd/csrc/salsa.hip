@@ -158,7 +158,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     SBTV_TRY(ws_get_t(ctx, "salsa.frozen", (size_t)batch, &frozen_d));
     SBTV_HIP(ctx, hipMemsetAsync(frozen_d, 0, sizeof(int) * batch, ctx->stream));
     const int nrb = fft_rows_blocks(fp);
-    const int npb = ew_blocks(P);
+    const int npb = fft_cols_blocks(fp);      // partial sums per image of the fused column/bookkeeping pass
     double *acc = nullptr, *postp = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.acc", (size_t)batch * 3 * nrb, &acc));
     SBTV_TRY(ws_get_t(ctx, "salsa.post", (size_t)batch * 6 * npb, &postp));
@@ -295,9 +295,16 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         a.frozen = frozen_d;
         SBTV_TRY(fft_cols_fwd_f(ctx, fp, u, bu, S, frozen_d));
         SBTV_TRY(fft_rows(ctx, fp, S, S, a));
-        SBTV_TRY(fft_cols_inv_f(ctx, fp, S, xn, inv_scale, frozen_d));
-        // (3) bu update, next prox input, sums incl. TVnorm(u) (:440-451)
-        SBTV_TRY(salsa_post(ctx, xn, crit2 ? xprev : nullptr, u, bu, g, td, postp, M, N, batch, frozen_d));
+        // (3) inverse column pass fused with the bu update, the next prox input and the sums
+        //     incl. TVnorm(u) (:440-451), while x is still in registers
+        ColsPost cp;
+        cp.u = u;
+        cp.bu = bu;
+        cp.g = g;
+        cp.tru = td;
+        cp.xprev = crit2 ? xprev : nullptr;
+        cp.partials = postp;
+        SBTV_TRY(fft_cols_inv_post(ctx, fp, S, xn, inv_scale, frozen_d, cp));
         Collect c{acc, nrb, nullptr, 0, postp, npb};
         // the collector writes the eight scalars straight into pinned host memory (no copy kernel);
         // they are visible to the host once ev_done has completed

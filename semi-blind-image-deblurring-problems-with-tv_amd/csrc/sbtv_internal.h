@@ -155,6 +155,18 @@ int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *plan);
 // `add` (optional) is added to `x` on load (x + add).
 int fft_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S);
 int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale);
+// inverse column pass fused with the SALSA bookkeeping pass (bu, g, reductions, TV(u)); see fft.hip
+struct ColsPost {
+    const double *u = nullptr;
+    double *bu = nullptr;
+    double *g = nullptr;
+    const double *tru = nullptr;
+    const double *xprev = nullptr;
+    double *partials = nullptr;      // [batch][6][fft_cols_blocks]
+};
+int fft_cols_blocks(const FftPlan &pl);
+int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
+                      const ColsPost &post);
 struct RowsArgs {
     int dir_fwd;            // 1: apply forward row FFT first
     int dir_inv;            // 1: apply inverse row FFT last
