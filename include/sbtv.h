@@ -172,6 +172,40 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                   double *x_out, double *objective, double *distance, double *times, double *mses,
                   int *numA, int *numAt, int *n_outer, int flags);
 
+/* ---- f-3: the other ADMM front-ends over the same kernels ----------------
+ * (never called by the reference's demos)  Only the TV paths exist
+ * ('TVINITIALIZATION*' = 1, P/PT = identity).  Images of a batch are solved one after another.
+ *
+ * sbtv_CSALSA_v2 replaces
+ *   [x,numA,numAt,objective,distance1,distance2,criterion,times,mses] = csalsa(y,A,mu1,mu2,sigma,
+ *      'AT',AT,'LS',invLS,'TVINITIALIZATION',1,'TVITERS',k,'STOPCRITERION',c,'TOLERANCEA',tol,
+ *      'MAXITERA',n,'CONTINUATIONFACTOR',delta,'EPSILON',eps,...)   (SALSA/CSALSA_v2.m:160-561)
+ * with invLS(r,mu) = real(ifft2(fft2(r)./(|H|^2+mu))) (:116 of its help, called as invLS(r,mu1) :471).
+ * opts: stopcriterion 1..3 (default of the reference: 3), maxiter, TViters, initialization, tolA and the
+ * Chambolle knobs are used; `speculate` is ignored.  Traces are 1-based like the reference: entry 0 is the
+ * state before the loop, the loop runs outer = 2..maxiter (:461).  All trace rows have maxiter entries.
+ * epsilon[b] = 0 selects sqrt(numel(y)+8*sqrt(numel(y)))*sigma[b] (:413).  n_outer[b] = last `outer`. */
+int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
+                   const double *taps, int taille, const double *mu1, const double *mu2,
+                   const double *sigma, const double *epsilon, double continuationfactor,
+                   const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                   double *x_out, double *objective, double *distance1, double *distance2,
+                   double *criterion, double *times, double *mses,
+                   int *numA, int *numAt, int *n_outer, int flags);
+
+/* sbtv_CoRAL_v2 replaces
+ *   [x,numA,numAt,objective,distance,times,mses] = CoRAL(y,A,tau1,tau2,'MU1',mu1,'MU2',mu2,'AT',AT,
+ *      'LS',invLS,'TVINITIALIZATION1',1,'TVITERS1',k1,'TVINITIALIZATION2',1,'TVITERS2',k2,...)
+ *   (SALSA/CoRAL_v2.m:2-476), invLS(r) = real(ifft2(fft2(r)./(|H|^2+mu_ls))), mu_ls = mu1+mu2 (:137)
+ * when mu_ls is NULL.  opts->TViters is TViters1; TViters2 is a separate argument.
+ * objective/times/mses: [batch*(maxiter+1)]; distance: [batch*maxiter*2], entry (outer-1)*2+{0,1}. */
+int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
+                  const double *taps, int taille, const double *tau1, const double *tau2,
+                  const double *mu1, const double *mu2, const double *mu_ls, int TViters2,
+                  const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                  double *x_out, double *objective, double *distance, double *times, double *mses,
+                  int *numA, int *numAt, int *n_outer, int flags);
+
 /* ---- a-8: FISTA with the TV prox ----------------------------------------
  * Replaces my_fista(b,A,AT,tau,L,Phi,Psi,stopcriterion,tolerance,maxiters,true,verbose)
  * (SALSA/my_fista.m:5-56) with Psi = cold-start Chambolle(prox_iters) and Phi = TVnorm

@@ -507,6 +507,168 @@ def SALSA_v2(y, A, tau, mu=1e-3, AT=None, invLS=None, true_x=None,
                 criterion=np.array(criterion))
 
 
+def CSALSA_v2(y, A, mu1, mu2, sigma, AT=None, invLS=None, true_x=None, stopcriterion=3, tolA=0.001,
+              maxiter=10000, TViters=5, initialization=0, continuationfactor=1.0, epsilon=0.0):
+    """SALSA/CSALSA_v2.m:160-561 (`csalsa`, constrained problem min TV(x) s.t. ||Ax-y|| <= epsilon) with
+    'TVINITIALIZATION' = 1 and P = PT = identity.  `invLS(r, mu)` takes the weight as second argument
+    (:310,471).  All traces are 1-based in MATLAB: index 0 here is the state before the loop, and the loop
+    runs outer = 2..maxiter (:461), i.e. at most maxiter-1 updates."""
+    if stopcriterion not in (1, 2, 3):
+        raise ValueError("Unknown stopping criterion")                   # :258
+    if AT is None:
+        raise ValueError("The function handle for transpose of A is missing")
+    if invLS is None:
+        raise ValueError("(A^T A + \\mu I)^(-1) must be specified as a function handle.")
+    numA = numAt = 0
+    ATy = AT(y)                                                          # :301
+    numAt += 1
+    dummy = invLS(ATy, mu1)                                              # :310
+    if dummy.shape != ATy.shape:
+        raise ValueError("Specified function handle for solving the LS step does not seem compatible")
+    phi = TVnorm                                                         # :371
+    if isinstance(initialization, np.ndarray):
+        x = np.array(initialization, dtype=np.float64)
+    elif initialization == 0:
+        x = AT(np.zeros_like(y))                                         # :380
+    elif initialization == 2:
+        x = ATy.copy()                                                   # :384
+        numAt += 1
+    else:
+        raise ValueError("Unknown 'Initialization' option")
+    u = np.zeros_like(x)                                                 # :404-408
+    bu = np.zeros_like(x)
+    v = np.zeros_like(y)
+    bv = np.zeros_like(y)
+    if not epsilon:
+        epsilon = math.sqrt(y.size + 8 * math.sqrt(y.size)) * sigma      # :413
+    Ax = A(x)                                                            # :416
+    numA += 1                                                            # :421
+    objective = [phi(x)]                                                 # :423
+    mses = [float(np.sum((x - true_x) ** 2)) / x.size] if true_x is not None else []   # :436
+    pux = np.zeros_like(u)
+    puy = np.zeros_like(u)
+    Ax = A(x)                                                            # :444
+    numA += 1
+    criterion = [float(np.linalg.norm((Ax - y).ravel()))]                # :446
+    distance1 = [float(np.linalg.norm((Ax - y - v).ravel()))]            # :447
+    distance2 = [float(np.linalg.norm((x - u).ravel()))]                 # :448
+    delta = continuationfactor
+    n_outer = 1
+    for outer in range(2, int(maxiter) + 1):                             # :461
+        n_outer = outer
+        xprev = x
+        r = mu1 * (u + bu) + mu2 * AT(y + v + bv)                        # :467
+        numAt += 1
+        x = invLS(r, mu1)                                                # :471
+        u, pux, puy = chambolle_prox_TV_stop(np.real(x - bu), lam=1.0 / mu1, maxiter=TViters,
+                                             dualvars=np.hstack([pux, puy]))          # :476
+        Ax = A(x)                                                        # :481
+        numA += 1
+        ve = Ax - y - bv                                                 # :483
+        n_ve = float(np.linalg.norm(ve.ravel()))
+        v = ve if n_ve <= epsilon else ve / n_ve * epsilon               # :485-489
+        bv = bv - (Ax - y - v)                                           # :491
+        bu = bu - (x - u)                                                # :492
+        criterion.append(float(np.linalg.norm((Ax - y).ravel())))        # :494
+        distance1.append(float(np.linalg.norm((Ax - y - v).ravel())))    # :495
+        distance2.append(float(np.linalg.norm((x - u).ravel())))         # :497
+        objective.append(phi(x))                                         # :498
+        if true_x is not None:
+            mses.append(float(np.linalg.norm((x - true_x).ravel())) ** 2 / true_x.size)   # :501
+        mu1 = mu1 * delta                                                # :517-518
+        mu2 = mu2 * delta
+        k = outer - 1                                                    # 0-based position of `outer`
+        if stopcriterion == 1:
+            sc = abs(objective[k] - objective[k - 1]) / objective[k]     # :527
+        elif stopcriterion == 2:
+            sc = abs(float(np.linalg.norm((x - xprev).ravel())) / float(np.linalg.norm(x.ravel())))   # :534
+        else:
+            sc = abs(criterion[k] - criterion[k - 1]) / criterion[k]     # :539
+        if sc < tolA and criterion[k] <= epsilon:                        # :529,535,541
+            break
+    return dict(x=x, numA=numA, numAt=numAt, objective=np.array(objective), distance1=np.array(distance1),
+                distance2=np.array(distance2), criterion=np.array(criterion), mses=np.array(mses),
+                n_outer=n_outer, epsilon=epsilon, u=u, v=v)
+
+
+def CoRAL_v2(y, A, tau1, tau2, mu1=1e-3, mu2=1e-3, AT=None, invLS=None, true_x=None, stopcriterion=1,
+             tolA=0.001, maxiter=10000, TViters1=5, TViters2=5, initialization=0):
+    """SALSA/CoRAL_v2.m:2-476 (compound regulariser, two TV terms: 'TVINITIALIZATION1' = 'TVINITIALIZATION2' = 1,
+    P1 = P2 = identity).  Note the initial scaled multipliers are bu = u = x and bv = v = x (:353-359),
+    not zero as in SALSA_v2."""
+    if stopcriterion not in (1, 2, 3):
+        raise ValueError("Unknown stopping criterion")                   # :133
+    if AT is None:
+        raise ValueError("The function handle for transpose of A is missing")
+    if invLS is None:
+        raise ValueError("(A^T A + \\mu I)^(-1) must be specified as a function handle.")
+    numA = numAt = 0
+    ATy = AT(y)                                                          # :189
+    numAt += 1
+    dummy = invLS(ATy)                                                   # :199
+    if dummy.shape != ATy.shape:
+        raise ValueError("Specified function handle for solving the LS step does not seem compatible")
+    ATy = AT(y)                                                          # :219 (computed twice)
+    numAt += 1
+    if isinstance(initialization, np.ndarray):
+        x = np.array(initialization, dtype=np.float64)
+    elif initialization == 0:
+        x = AT(np.zeros_like(y))                                         # :329
+    elif initialization == 2:
+        x = ATy.copy()                                                   # :333
+    else:
+        raise ValueError("Unknown 'Initialization' option")
+    u = x.copy()                                                         # :353-361
+    bu = u.copy()
+    threshold1 = tau1 / mu1
+    v = x.copy()
+    bv = v.copy()
+    threshold2 = tau2 / mu2
+    resid = y - A(x)                                                     # :366
+    numA += 1
+    objective = [0.5 * float(np.sum(resid * resid)) + tau1 * TVnorm(u) + tau2 * TVnorm(v)]   # :368
+    mses = [float(np.sum((x - true_x) ** 2)) / x.size] if true_x is not None else []
+    pux = np.zeros_like(u)
+    puy = np.zeros_like(u)
+    pvx = np.zeros_like(v)
+    pvy = np.zeros_like(v)
+    distance = []
+    criterion = [1.0]
+    n_outer = 0
+    for outer in range(1, int(maxiter) + 1):                             # :394
+        n_outer = outer
+        xprev = x
+        u, pux, puy = chambolle_prox_TV_stop(np.real(x - bu), lam=threshold1, maxiter=TViters1,
+                                             dualvars=np.hstack([pux, puy]))          # :401
+        v, pvx, pvy = chambolle_prox_TV_stop(np.real(x - bv), lam=threshold2, maxiter=TViters2,
+                                             dualvars=np.hstack([pvx, pvy]))          # :406
+        r = ATy + mu1 * (u + bu) + mu2 * (v + bv)                        # :411
+        x = invLS(r)                                                     # :413
+        bu = bu + (u - x)                                                # :420
+        bv = bv + (v - x)                                                # :421
+        resid = y - A(x)                                                 # :423
+        numA += 1
+        objective.append(0.5 * float(np.sum(resid * resid)) + tau1 * TVnorm(u) + tau2 * TVnorm(v))   # :425
+        if true_x is not None:
+            e = x - true_x
+            mses.append(float(np.sum(e * e)) / x.size)                   # :428-429
+        nx2 = float(np.sum(x * x))
+        distance.append((float(np.linalg.norm((x - u).ravel())) / math.sqrt(nx2 + float(np.sum(u * u))),
+                         float(np.linalg.norm((x - v).ravel())) / math.sqrt(nx2 + float(np.sum(v * v)))))   # :432-433
+        if outer > 1:                                                    # :435
+            if stopcriterion == 1:
+                crit = abs(objective[outer] - objective[outer - 1]) / objective[outer - 1]   # :441
+            elif stopcriterion == 2:
+                crit = abs(float(np.linalg.norm((x - xprev).ravel())) / float(np.linalg.norm(x.ravel())))
+            else:
+                crit = objective[outer]
+            criterion.append(crit)
+            if crit < tolA:                                              # :453
+                break
+    return dict(x=x, numA=numA, numAt=numAt, objective=np.array(objective), distance=np.array(distance),
+                mses=np.array(mses), n_outer=n_outer, u=u, v=v, criterion=np.array(criterion))
+
+
 def my_fista(b, A, AT, tau, L, Phi, Psi, stopcriterion, tolerance, maxiters, true, x0=None):
     """SALSA/my_fista.m:5-56.  `x0=None` -> x = AT(b) (:7); passing zeros gives
     the my_deblur_fista.m:21 start."""

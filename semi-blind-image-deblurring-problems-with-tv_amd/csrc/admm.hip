@@ -1,0 +1,677 @@
+// The two other ADMM front-ends of the SALSA toolbox that call the Chambolle TV prox, built from
+// the same device kernels as SALSA_v2:
+//   C-SALSA  (SALSA/CSALSA_v2.m:160-561)  min TV(x)  s.t. ||Ax - y|| <= epsilon
+//   CoRAL    (SALSA/CoRAL_v2.m:2-476)     min 0.5||Ax-y||^2 + tau1 TV(x) + tau2 TV(x)   (two split copies)
+// Neither is called by the reference's demos, so they are written for clarity rather than fused to the
+// last pass: per outer iteration the host reads back a handful of scalars and applies the stop rule
+// (no speculation), and the images of a batch are solved one after another.
+#include <chrono>
+#include <cmath>
+
+#include "sbtv_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace sbtv {
+
+namespace {
+
+constexpr int AB = 256;
+
+__device__ __forceinline__ double ad_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-reduce NQ running sums and store them as partials[q * gridDim.x + blockIdx.x]
+template <int NQ>
+__device__ __forceinline__ void ad_store_partials(double (&acc)[NQ], double *__restrict__ partials) {
+    __shared__ double red[NQ * 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        const double a = ad_wave_sum(acc[c]);
+        if (lane == 0) red[c * 4 + w] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c)
+            partials[(size_t)c * gridDim.x + blockIdx.x] = (red[c * 4] + red[c * 4 + 1]) + (red[c * 4 + 2] + red[c * 4 + 3]);
+    }
+}
+
+#define AD_LOOP(q, P) for (size_t q = (size_t)blockIdx.x * AB + threadIdx.x; q < (P) / 2; q += (size_t)gridDim.x * AB)
+#define AD_LD(p, q) (*reinterpret_cast<const double2 *>((p) + 2 * (q)))
+#define AD_ST(p, q, v) (*reinterpret_cast<double2 *>((p) + 2 * (q)) = (v))
+
+// g = x - b
+__global__ __launch_bounds__(AB) void ad_sub_kernel(const double *__restrict__ x, const double *__restrict__ b,
+                                                     double *__restrict__ g, size_t P) {
+    AD_LOOP(q, P) {
+        const double2 xv = AD_LD(x, q), bv = AD_LD(b, q);
+        AD_ST(g, q, make_double2(xv.x - bv.x, xv.y - bv.y));
+    }
+}
+
+// ---- C-SALSA -----------------------------------------------------------------------------------
+// w = mu2 * (y + v + bv)                                                   (CSALSA_v2.m:467)
+__global__ __launch_bounds__(AB) void csalsa_w_kernel(const double *__restrict__ y, const double *__restrict__ v,
+                                                       const double *__restrict__ bv, const double *__restrict__ par,
+                                                       double *__restrict__ w, size_t P) {
+    const double mu2 = par[1];
+    AD_LOOP(q, P) {
+        const double2 a = AD_LD(y, q), b = AD_LD(v, q), c = AD_LD(bv, q);
+        AD_ST(w, q, make_double2(mu2 * ((a.x + b.x) + c.x), mu2 * ((a.y + b.y) + c.y)));
+    }
+}
+
+// partials[nb] = sum (Ax - y - bv)^2                                        (:483-484)
+__global__ __launch_bounds__(AB) void csalsa_ve_kernel(const double *__restrict__ Ax, const double *__restrict__ y,
+                                                        const double *__restrict__ bv, double *__restrict__ partials,
+                                                        size_t P) {
+    double acc[1] = {0.0};
+    AD_LOOP(q, P) {
+        const double2 a = AD_LD(Ax, q), b = AD_LD(y, q), c = AD_LD(bv, q);
+        const double e0 = (a.x - b.x) - c.x, e1 = (a.y - b.y) - c.y;
+        acc[0] += e0 * e0 + e1 * e1;
+    }
+    ad_store_partials<1>(acc, partials);
+}
+
+// projection of ve on the epsilon ball, multiplier updates and the sums of the traces (:483-501,534)
+//   partials [6][nb]: (Ax-y)^2, (Ax-y-v)^2, (x-u)^2, (x-true)^2, (x-xprev)^2, x^2
+__global__ __launch_bounds__(AB) void csalsa_update_kernel(const double *__restrict__ Ax, const double *__restrict__ y,
+                                                            const double *__restrict__ x, const double *__restrict__ u,
+                                                            double *__restrict__ v, double *__restrict__ bv,
+                                                            double *__restrict__ bu, const double *__restrict__ tru,
+                                                            const double *__restrict__ xprev,
+                                                            const double *__restrict__ nve2, double eps,
+                                                            double *__restrict__ partials, size_t P) {
+    const double n_ve = sqrt(nve2[0]);
+    const bool inside = n_ve <= eps;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    AD_LOOP(q, P) {
+        const double2 a = AD_LD(Ax, q), yy = AD_LD(y, q), c = AD_LD(bv, q);
+        const double t0 = a.x - yy.x, t1 = a.y - yy.y;
+        const double e0 = t0 - c.x, e1 = t1 - c.y;
+        const double v0 = inside ? e0 : e0 / n_ve * eps, v1 = inside ? e1 : e1 / n_ve * eps;
+        AD_ST(v, q, make_double2(v0, v1));
+        const double r0 = t0 - v0, r1 = t1 - v1;
+        AD_ST(bv, q, make_double2(c.x - r0, c.y - r1));
+        const double2 xv = AD_LD(x, q), uv = AD_LD(u, q), bb = AD_LD(bu, q);
+        const double d0 = xv.x - uv.x, d1 = xv.y - uv.y;
+        AD_ST(bu, q, make_double2(bb.x - d0, bb.y - d1));
+        acc[0] += t0 * t0 + t1 * t1;
+        acc[1] += r0 * r0 + r1 * r1;
+        acc[2] += d0 * d0 + d1 * d1;
+        if (tru) {
+            const double2 tv = AD_LD(tru, q);
+            const double m0 = xv.x - tv.x, m1 = xv.y - tv.y;
+            acc[3] += m0 * m0 + m1 * m1;
+        }
+        if (xprev) {
+            const double2 xo = AD_LD(xprev, q);
+            const double m0 = xv.x - xo.x, m1 = xv.y - xo.y;
+            acc[4] += m0 * m0 + m1 * m1;
+        }
+        acc[5] += xv.x * xv.x + xv.y * xv.y;
+    }
+    ad_store_partials<6>(acc, partials);
+}
+
+// ---- CoRAL -------------------------------------------------------------------------------------
+// s = (mu1 (u+bu) + mu2 (v+bv)) / mu_ls                                     (CoRAL_v2.m:411, ATy enters spectrally)
+__global__ __launch_bounds__(AB) void coral_s_kernel(const double *__restrict__ u, const double *__restrict__ bu,
+                                                      const double *__restrict__ v, const double *__restrict__ bv,
+                                                      double mu1, double mu2, double mu_ls, double *__restrict__ s,
+                                                      size_t P) {
+    AD_LOOP(q, P) {
+        const double2 a = AD_LD(u, q), b = AD_LD(bu, q), c = AD_LD(v, q), d = AD_LD(bv, q);
+        AD_ST(s, q, make_double2((mu1 * (a.x + b.x) + mu2 * (c.x + d.x)) / mu_ls,
+                                 (mu1 * (a.y + b.y) + mu2 * (c.y + d.y)) / mu_ls));
+    }
+}
+
+// bu += u - x ; bv += v - x ; g1 = x - bu ; g2 = x - bv  (:420-421 and the next prox inputs :401,406)
+//   partials [7][nb]: (x-true)^2, (x-u)^2, (x-v)^2, x^2, u^2, v^2, (x-xprev)^2
+__global__ __launch_bounds__(AB) void coral_post_kernel(const double *__restrict__ x, const double *__restrict__ xprev,
+                                                         const double *__restrict__ u, const double *__restrict__ v,
+                                                         double *__restrict__ bu, double *__restrict__ bv,
+                                                         double *__restrict__ g1, double *__restrict__ g2,
+                                                         const double *__restrict__ tru, double *__restrict__ partials,
+                                                         size_t P) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    AD_LOOP(q, P) {
+        const double2 xv = AD_LD(x, q), uv = AD_LD(u, q), vv = AD_LD(v, q);
+        double2 b1 = AD_LD(bu, q), b2 = AD_LD(bv, q);
+        b1.x = b1.x + (uv.x - xv.x);
+        b1.y = b1.y + (uv.y - xv.y);
+        b2.x = b2.x + (vv.x - xv.x);
+        b2.y = b2.y + (vv.y - xv.y);
+        AD_ST(bu, q, b1);
+        AD_ST(bv, q, b2);
+        AD_ST(g1, q, make_double2(xv.x - b1.x, xv.y - b1.y));
+        AD_ST(g2, q, make_double2(xv.x - b2.x, xv.y - b2.y));
+        if (tru) {
+            const double2 tv = AD_LD(tru, q);
+            const double m0 = xv.x - tv.x, m1 = xv.y - tv.y;
+            acc[0] += m0 * m0 + m1 * m1;
+        }
+        {
+            const double d0 = xv.x - uv.x, d1 = xv.y - uv.y;
+            acc[1] += d0 * d0 + d1 * d1;
+            const double e0 = xv.x - vv.x, e1 = xv.y - vv.y;
+            acc[2] += e0 * e0 + e1 * e1;
+        }
+        acc[3] += xv.x * xv.x + xv.y * xv.y;
+        acc[4] += uv.x * uv.x + uv.y * uv.y;
+        acc[5] += vv.x * vv.x + vv.y * vv.y;
+        if (xprev) {
+            const double2 xo = AD_LD(xprev, q);
+            const double m0 = xv.x - xo.x, m1 = xv.y - xo.y;
+            acc[6] += m0 * m0 + m1 * m1;
+        }
+    }
+    ad_store_partials<7>(acc, partials);
+}
+
+inline int ad_blocks(size_t P) {
+    size_t nb = (P / 2 + AB - 1) / AB;
+    if (nb > 1024) nb = 1024;
+    return nb < 1 ? 1 : (int)nb;
+}
+
+// everything one single-image solve shares: plans, spectra of the PSF and of y
+struct AdmmCommon {
+    FftPlan fp;
+    size_t P;
+    double2 *S, *Hs, *Ys;
+    double *taps_d;
+    double inv_scale, parseval;
+};
+
+int admm_common(sbtv_ctx *ctx, int M, int N, const double *taps, int taille, const double *yd, AdmmCommon *c) {
+    SBTV_TRY(fft_plan(ctx, M, N, 1, &c->fp));
+    c->P = (size_t)M * N;
+    SBTV_TRY(ws_get_t(ctx, "admm.S", c->P / 2, &c->S));
+    SBTV_TRY(ws_get_t(ctx, "admm.H", (size_t)(c->fp.n1 + 1) * N, &c->Hs));
+    SBTV_TRY(ws_get_t(ctx, "admm.Y", (size_t)(c->fp.n1 + 1) * N, &c->Ys));
+    SBTV_TRY(ws_get_t(ctx, "admm.taps", (size_t)taille * taille, &c->taps_d));
+    SBTV_HIP(ctx, hipMemcpyAsync(c->taps_d, taps, sizeof(double) * taille * taille, hipMemcpyHostToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->inv_scale = 1.0 / ((double)c->fp.n1 * N);
+    c->parseval = 1.0 / ((double)M * N);
+    SBTV_TRY(psf_spectrum(ctx, c->fp, c->taps_d, taille, c->Hs));
+    if (yd) {
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.op = OP_NONE;
+        SBTV_TRY(fft_cols_fwd(ctx, c->fp, yd, nullptr, c->S));
+        SBTV_TRY(fft_rows(ctx, c->fp, c->S, c->S, a));
+        SBTV_TRY(spec_unpack(ctx, c->fp, c->S, c->Ys));
+    }
+    return 0;
+}
+
+// out = real(ifft2(op(H) .* fft2(in)))
+int admm_apply(sbtv_ctx *ctx, const AdmmCommon &c, int op, const double *in, double *out) {
+    RowsArgs a{};
+    a.dir_fwd = 1;
+    a.dir_inv = 1;
+    a.op = op;
+    a.H = c.Hs;
+    SBTV_TRY(fft_cols_fwd(ctx, c.fp, in, nullptr, c.S));
+    SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
+    return fft_cols_inv(ctx, c.fp, c.S, out, c.inv_scale);
+}
+
+int admm_init_x(sbtv_ctx *ctx, const AdmmCommon &c, int initialization, const double *yd, const double *xi, double *x) {
+    if (initialization == 0) {
+        SBTV_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * c.P, ctx->stream));   // AT(zeros) == 0
+    } else if (initialization == 2) {
+        SBTV_TRY(admm_apply(ctx, c, OP_MUL_HC, yd, x));                            // x = ATy
+    } else {
+        SBTV_HIP(ctx, hipMemcpyAsync(x, xi, sizeof(double) * c.P, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return 0;
+}
+
+int check_common(sbtv_ctx *ctx, const char *who, const double *y, const double *taps, const sbtv_salsa_opts *opts,
+                 const double *x_init, int M, int N, int batch, int taille) {
+    if (!y || !opts || batch < 1) return fail(ctx, SBTV_ERR_BADARG, std::string(who) + ": missing required argument");
+    if (!taps) return fail(ctx, SBTV_ERR_MISSING_AT, "The function handle for transpose of A is missing");
+    if (opts->stopcriterion < 1 || opts->stopcriterion > 3) return fail(ctx, SBTV_ERR_STOPCRITERION, "Unknown stopping criterion");
+    if (opts->initialization != 0 && opts->initialization != 2 && opts->initialization != 33333)
+        return fail(ctx, SBTV_ERR_INIT, "Unknown 'Initialization' option");
+    if (opts->initialization == 33333 && !x_init) return fail(ctx, SBTV_ERR_INIT, "Initialization = array but x_init is NULL");
+    if (opts->TViters <= 0) return fail(ctx, SBTV_ERR_MAXITER, std::string(who) + ": TViters must be positive");
+    if (opts->maxiter < 1) return fail(ctx, SBTV_ERR_MAXITER, std::string(who) + ": maxiter must be positive");
+    if (taille < 1 || taille > 15 || taille > M || taille > N) return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps, int taille, double mu1, double mu2,
+               double sigma, double epsilon, double delta, const sbtv_salsa_opts *opts, const double *td,
+               const double *xi, double *x_out_dev, double *objective, double *distance1, double *distance2,
+               double *criterion, double *times, double *mses, int *numA, int *numAt, int *n_outer) {
+    AdmmCommon c;
+    SBTV_TRY(admm_common(ctx, M, N, taps, taille, nullptr, &c));
+    ProxPlan pp;
+    SBTV_TRY(prox_plan(ctx, M, N, 1, &pp));
+    const size_t P = c.P;
+    const int nb = ad_blocks(P);
+    double *xbuf[2], *u, *bu, *v, *bv, *w, *Ax, *g, *par, *partials, *sums, *acc;
+    double2 *Ws;
+    SBTV_TRY(ws_get_t(ctx, "admm.acc", (size_t)3 * fft_rows_blocks(c.fp), &acc));
+    SBTV_TRY(ws_get_t(ctx, "admm.x0", P, &xbuf[0]));
+    SBTV_TRY(ws_get_t(ctx, "admm.x1", P, &xbuf[1]));
+    SBTV_TRY(ws_get_t(ctx, "admm.u", P, &u));
+    SBTV_TRY(ws_get_t(ctx, "admm.bu", P, &bu));
+    SBTV_TRY(ws_get_t(ctx, "admm.v", P, &v));
+    SBTV_TRY(ws_get_t(ctx, "admm.bv", P, &bv));
+    SBTV_TRY(ws_get_t(ctx, "admm.w", P, &w));
+    SBTV_TRY(ws_get_t(ctx, "admm.Ax", P, &Ax));
+    SBTV_TRY(ws_get_t(ctx, "admm.g", P, &g));
+    SBTV_TRY(ws_get_t(ctx, "admm.par", (size_t)4, &par));               // mu1, mu2, 1/mu1
+    SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
+    SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)16, &sums));            // [0..5] update sums, [6] TV(x), [8] n_ve^2
+    SBTV_TRY(ws_get_t(ctx, "admm.W", (size_t)(c.fp.n1 + 1) * N, &Ws));
+    double *hs = nullptr;
+    {
+        void *pz = nullptr;
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * 16, &pz));
+        hs = static_cast<double *>(pz);
+    }
+    const int maxiter = opts->maxiter;
+    if (!(epsilon != 0.0)) epsilon = sqrt((double)P + 8 * sqrt((double)P)) * sigma;              // :413
+    auto upload_par = [&]() -> int {
+        const double h[4] = {mu1, mu2, 1.0 / mu1, 0.0};
+        SBTV_HIP(ctx, hipMemcpyAsync(par, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    SBTV_TRY(upload_par());
+    int h_numA = 0, h_numAt = 1;                                         // ATy (:301)
+    ctx->calls += 2;                                                     // AT(y), invLS(ATy, mu1) (:301,310)
+    double *x = xbuf[0];
+    SBTV_TRY(admm_init_x(ctx, c, opts->initialization, yd, xi, x));
+    if (opts->initialization == 0) ctx->calls += 1;
+    if (opts->initialization == 2) h_numAt += 1;                         // :385
+    SBTV_HIP(ctx, hipMemsetAsync(u, 0, sizeof(double) * P, ctx->stream));   // :404-408
+    SBTV_HIP(ctx, hipMemsetAsync(bu, 0, sizeof(double) * P, ctx->stream));
+    SBTV_HIP(ctx, hipMemsetAsync(v, 0, sizeof(double) * P, ctx->stream));
+    SBTV_HIP(ctx, hipMemsetAsync(bv, 0, sizeof(double) * P, ctx->stream));
+    SBTV_TRY(prox_zero_duals(ctx, pp));                                  // :440-441
+    SBTV_TRY(prox_reset(ctx, pp, par + 2, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
+
+    // state before the loop (:416-448): Ax, criterion(1), objective(1) = TV(x), mses(1), distances
+    SBTV_TRY(admm_apply(ctx, c, OP_MUL_H, x, Ax));
+    h_numA += 2;                                                         // :421,445
+    ctx->calls += 2;
+    {
+        // v = 0, bv = 0, u = 0: the update kernel on scratch multipliers gives the three norms without side effects
+        double *sv, *sbv, *sbu;
+        SBTV_TRY(ws_get_t(ctx, "admm.scratch0", P, &sv));
+        SBTV_TRY(ws_get_t(ctx, "admm.scratch1", P, &sbv));
+        SBTV_TRY(ws_get_t(ctx, "admm.scratch2", P, &sbu));
+        SBTV_HIP(ctx, hipMemsetAsync(sbv, 0, sizeof(double) * P, ctx->stream));
+        SBTV_HIP(ctx, hipMemsetAsync(sbu, 0, sizeof(double) * P, ctx->stream));
+        SBTV_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(double) * 16, ctx->stream));   // n_ve^2 = 0 -> inside the ball, v = ve
+        hipLaunchKernelGGL(csalsa_update_kernel, dim3(nb), dim3(AB), 0, ctx->stream, Ax, yd, x, u, sv, sbv, sbu, td,
+                           (const double *)nullptr, sums + 8, 1.0, partials, P);
+        SBTV_TRY(reduce_partials(ctx, partials, 6, nb, sums));
+        SBTV_TRY(tvnorm_dev(ctx, x, M, N, 1, sums + 6));
+        SBTV_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // before the loop v = 0, so distance1(1) = ||Ax-y-v|| = ||Ax-y|| (:447); hs[1] is not that (v=ve there)
+        if (criterion) criterion[0] = sqrt(hs[0]);
+        if (distance1) distance1[0] = sqrt(hs[0]);
+        if (distance2) distance2[0] = sqrt(hs[2]);                       // ||x - u||, u = 0 (:448)
+        if (objective) objective[0] = hs[6];                             // phi(x) = TVnorm(x) (:423)
+        if (mses && td) mses[0] = hs[3] / (double)P;                     // :436
+        if (times) times[0] = 0.0;
+    }
+    double crit_prev = sqrt(hs[0]), obj_prev = hs[6];
+    const auto t0 = std::chrono::steady_clock::now();
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    int last = 1;
+    long long prox_iters = 0;
+    for (int outer = 2; outer <= maxiter; ++outer) {                     // :461
+        last = outer;
+        const int k = outer - 1;
+        double *xn = xbuf[k & 1];
+        const double *xprev = xbuf[(k & 1) ^ 1];
+        // r = mu1 (u+bu) + mu2 AT(y+v+bv) ; x = invLS(r, mu1)   (:467-471), all in one spectral pass:
+        //   X = (conj(H) W + mu1 S) / (|H|^2 + mu1),  W = fft2(mu2 (y+v+bv)),  S = fft2(u+bu)
+        hipLaunchKernelGGL(csalsa_w_kernel, dim3(nb), dim3(AB), 0, ctx->stream, yd, v, bv, par, w, P);
+        {
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.op = OP_NONE;
+            SBTV_TRY(fft_cols_fwd(ctx, c.fp, w, nullptr, c.S));
+            SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
+            SBTV_TRY(spec_unpack(ctx, c.fp, c.S, Ws));
+        }
+        {
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.dir_inv = 1;
+            a.op = OP_SALSA;
+            a.H = c.Hs;
+            a.Y = Ws;
+            a.mu = par;                                                  // mu1
+            a.acc = acc;                                                 // residual sum of OP_SALSA, not used here
+            SBTV_TRY(fft_cols_fwd(ctx, c.fp, u, bu, c.S));
+            SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
+            SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
+        }
+        h_numAt += 1;
+        // u = prox_{TV/mu1}(x - bu), warm-started duals (:476)
+        hipLaunchKernelGGL(ad_sub_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, bu, g, P);
+        SBTV_TRY(prox_reset(ctx, pp, par + 2, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u));
+        // Ax, projection on the epsilon ball, multipliers, traces (:481-501)
+        SBTV_TRY(admm_apply(ctx, c, OP_MUL_H, xn, Ax));
+        h_numA += 1;
+        ctx->calls += 3;                                                 // AT, invLS, A
+        hipLaunchKernelGGL(csalsa_ve_kernel, dim3(nb), dim3(AB), 0, ctx->stream, Ax, yd, bv, partials, P);
+        SBTV_TRY(reduce_partials(ctx, partials, 1, nb, sums + 8));
+        hipLaunchKernelGGL(csalsa_update_kernel, dim3(nb), dim3(AB), 0, ctx->stream, Ax, yd, xn, u, v, bv, bu, td,
+                           (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, sums + 8, epsilon, partials, P);
+        SBTV_TRY(reduce_partials(ctx, partials, 6, nb, sums));
+        SBTV_TRY(tvnorm_dev(ctx, xn, M, N, 1, sums + 6));
+        SBTV_HIP(ctx, hipGetLastError());
+        SBTV_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(hs + 8, pp.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        prox_iters += *reinterpret_cast<const int *>(hs + 8);
+        const double crit = sqrt(hs[0]), obj = hs[6];
+        if (criterion) criterion[k] = crit;                              // :494
+        if (distance1) distance1[k] = sqrt(hs[1]);                       // :495
+        if (distance2) distance2[k] = sqrt(hs[2]);                       // :497
+        if (objective) objective[k] = obj;                               // :498
+        if (mses && td) mses[k] = hs[3] / (double)P;                     // :501
+        if (times) times[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (delta != 1.0) {                                              // :517-518
+            mu1 *= delta;
+            mu2 *= delta;
+            SBTV_TRY(upload_par());
+        }
+        double sc;
+        if (opts->stopcriterion == 1)
+            sc = fabs(obj - obj_prev) / obj;                             // :527
+        else if (opts->stopcriterion == 2)
+            sc = fabs(sqrt(hs[4]) / sqrt(hs[5]));                        // :534
+        else
+            sc = fabs(crit - crit_prev) / crit;                          // :539
+        obj_prev = obj;
+        crit_prev = crit;
+        if (sc < opts->tolA && crit <= epsilon) break;                   // :529,535,541
+    }
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f;
+        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->timing[0] = ms;
+        ctx->timing[1] = 0.0;
+        ctx->timing[2] = (double)prox_iters;
+        ctx->timing[3] = 40.0 * (double)P * (double)prox_iters;
+    }
+    SBTV_HIP(ctx, hipMemcpyAsync(x_out_dev, xbuf[(last - 1) & 1], sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (numA) *numA = h_numA;
+    if (numAt) *numAt = h_numAt;
+    if (n_outer) *n_outer = last;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps, int taille, double tau1, double tau2,
+              double mu1, double mu2, double mu_ls, int TViters2, const sbtv_salsa_opts *opts, const double *td,
+              const double *xi, double *x_out_dev, double *objective, double *distance, double *times, double *mses,
+              int *numA, int *numAt, int *n_outer) {
+    AdmmCommon c;
+    SBTV_TRY(admm_common(ctx, M, N, taps, taille, yd, &c));
+    ProxPlan pu, pv;
+    SBTV_TRY(prox_plan(ctx, M, N, 1, &pu, "prox"));
+    SBTV_TRY(prox_plan(ctx, M, N, 1, &pv, "prox2"));
+    const size_t P = c.P;
+    const int nb = ad_blocks(P), nrb = fft_rows_blocks(c.fp);
+    double *xbuf[2], *u, *bu, *v, *bv, *s, *g1, *g2, *par, *partials, *sums, *acc;
+    SBTV_TRY(ws_get_t(ctx, "admm.x0", P, &xbuf[0]));
+    SBTV_TRY(ws_get_t(ctx, "admm.x1", P, &xbuf[1]));
+    SBTV_TRY(ws_get_t(ctx, "admm.u", P, &u));
+    SBTV_TRY(ws_get_t(ctx, "admm.bu", P, &bu));
+    SBTV_TRY(ws_get_t(ctx, "admm.v", P, &v));
+    SBTV_TRY(ws_get_t(ctx, "admm.bv", P, &bv));
+    SBTV_TRY(ws_get_t(ctx, "admm.w", P, &s));
+    SBTV_TRY(ws_get_t(ctx, "admm.g", P, &g1));
+    SBTV_TRY(ws_get_t(ctx, "admm.g2", P, &g2));
+    SBTV_TRY(ws_get_t(ctx, "admm.par", (size_t)4, &par));               // mu_ls, thr1, thr2
+    SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
+    SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)16, &sums));            // [0..6] post sums, [8] resid2, [9] TV(u), [10] TV(v)
+    SBTV_TRY(ws_get_t(ctx, "admm.acc", (size_t)3 * nrb, &acc));
+    double *hs = nullptr;
+    {
+        void *pz = nullptr;
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * 16, &pz));
+        hs = static_cast<double *>(pz);
+    }
+    {
+        const double h[4] = {mu_ls, tau1 / mu1, tau2 / mu2, 0.0};        // thresholds :356,361
+        SBTV_HIP(ctx, hipMemcpyAsync(par, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const int maxiter = opts->maxiter;
+    int h_numA = 0, h_numAt = 2;                                         // ATy twice (:189,219)
+    ctx->calls += 3;                                                     // AT(y), invLS(ATy), AT(y)
+    double *x = xbuf[0];
+    SBTV_TRY(admm_init_x(ctx, c, opts->initialization, yd, xi, x));
+    if (opts->initialization == 0) ctx->calls += 1;
+    // u = x ; bu = u ; v = x ; bv = v  (:353-359)  ->  first prox inputs x - bu = x - bv = 0
+    for (double *dst : {u, bu, v, bv})
+        SBTV_HIP(ctx, hipMemcpyAsync(dst, x, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipMemsetAsync(g1, 0, sizeof(double) * P, ctx->stream));
+    SBTV_HIP(ctx, hipMemsetAsync(g2, 0, sizeof(double) * P, ctx->stream));
+    SBTV_TRY(prox_zero_duals(ctx, pu));                                  // :384-392
+    SBTV_TRY(prox_zero_duals(ctx, pv));
+    SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
+    SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, TViters2, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
+
+    // initial objective (:366-368)
+    {
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.op = OP_RESID;
+        a.H = c.Hs;
+        a.Y = c.Ys;
+        a.acc = acc;
+        SBTV_TRY(fft_cols_fwd(ctx, c.fp, x, nullptr, c.S));
+        SBTV_TRY(fft_rows(ctx, c.fp, c.S, nullptr, a));
+        SBTV_TRY(reduce_partials(ctx, acc, 1, nrb, sums + 8));
+        SBTV_TRY(tvnorm_dev(ctx, u, M, N, 1, sums + 9));
+        SBTV_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(double) * 8, ctx->stream));
+        if (td) {
+            double *o4 = nullptr;
+            SBTV_TRY(ws_get_t(ctx, "admm.o4", (size_t)4, &o4));
+            SBTV_TRY(pair_sums(ctx, x, td, P, 1, o4));
+            SBTV_HIP(ctx, hipMemcpyAsync(sums, o4, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        SBTV_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        h_numA += 1;
+        ctx->calls += 1;
+        const double f0 = 0.5 * (hs[8] * c.parseval) + tau1 * hs[9] + tau2 * hs[9];   // u = v = x
+        if (objective) objective[0] = f0;
+        if (times) times[0] = 0.0;
+        if (mses && td) mses[0] = hs[0] / (double)P;                     // :381
+        hs[15] = f0;
+    }
+    double obj_prev = hs[15];
+    const auto t0 = std::chrono::steady_clock::now();
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    int last = 0;
+    long long prox_iters = 0;
+    for (int outer = 1; outer <= maxiter; ++outer) {                     // :394
+        last = outer;
+        double *xn = xbuf[outer & 1];
+        const double *xprev = xbuf[(outer & 1) ^ 1];
+        // the two TV proxes with their own warm-started duals (:401,406)
+        if (outer > 1) {
+            SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+            SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, TViters2, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+        }
+        SBTV_TRY(prox_iterate(ctx, pu, g1, opts->TViters, u));
+        SBTV_TRY(prox_iterate(ctx, pv, g2, TViters2, v));
+        // r = ATy + mu1 (u+bu) + mu2 (v+bv) ; x = invLS(r)   (:411-413)  + residual energy (:423, Parseval)
+        hipLaunchKernelGGL(coral_s_kernel, dim3(nb), dim3(AB), 0, ctx->stream, u, bu, v, bv, mu1, mu2, mu_ls, s, P);
+        {
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.dir_inv = 1;
+            a.op = OP_SALSA;
+            a.H = c.Hs;
+            a.Y = c.Ys;
+            a.mu = par;                                                  // mu_ls
+            a.acc = acc;
+            SBTV_TRY(fft_cols_fwd(ctx, c.fp, s, nullptr, c.S));
+            SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
+            SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
+        }
+        h_numA += 1;
+        ctx->calls += 2;                                                 // invLS, A
+        hipLaunchKernelGGL(coral_post_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn,
+                           (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, u, v, bu, bv, g1, g2, td, partials, P);
+        SBTV_TRY(reduce_partials(ctx, partials, 7, nb, sums));
+        SBTV_TRY(reduce_partials(ctx, acc, 1, nrb, sums + 8));
+        SBTV_TRY(tvnorm_dev(ctx, u, M, N, 1, sums + 9));
+        SBTV_TRY(tvnorm_dev(ctx, v, M, N, 1, sums + 10));
+        SBTV_HIP(ctx, hipGetLastError());
+        SBTV_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(hs + 12, pu.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(hs + 13, pv.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        prox_iters += *reinterpret_cast<const int *>(hs + 12) + *reinterpret_cast<const int *>(hs + 13);
+        const double f = 0.5 * (hs[8] * c.parseval) + tau1 * hs[9] + tau2 * hs[10];      // :425
+        if (objective) objective[outer] = f;
+        if (mses && td) mses[outer] = hs[0] / (double)P;                 // :428-429
+        if (distance) {
+            distance[(size_t)(outer - 1) * 2] = sqrt(hs[1]) / sqrt(hs[3] + hs[4]);       // :432
+            distance[(size_t)(outer - 1) * 2 + 1] = sqrt(hs[2]) / sqrt(hs[3] + hs[5]);   // :433
+        }
+        if (times) times[outer] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        bool stop = false;
+        if (outer > 1) {                                                 // :435
+            double crit;
+            if (opts->stopcriterion == 1)
+                crit = fabs(f - obj_prev) / obj_prev;                    // :441
+            else if (opts->stopcriterion == 2)
+                crit = fabs(sqrt(hs[6]) / sqrt(hs[3]));                  // :445
+            else
+                crit = f;                                                // :448
+            stop = crit < opts->tolA;                                    // :453
+        }
+        obj_prev = f;
+        if (stop) break;
+    }
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f;
+        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->timing[0] = ms;
+        ctx->timing[1] = 0.0;
+        ctx->timing[2] = (double)prox_iters;
+        ctx->timing[3] = 40.0 * (double)P * (double)prox_iters;
+    }
+    SBTV_HIP(ctx, hipMemcpyAsync(x_out_dev, xbuf[last & 1], sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (numA) *numA = h_numA;
+    if (numAt) *numAt = h_numAt;
+    if (n_outer) *n_outer = last;
+    return 0;
+}
+
+}  // namespace
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const double *taps, int taille,
+                   const double *mu1, const double *mu2, const double *sigma, const double *epsilon,
+                   double continuationfactor, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                   double *x_out, double *objective, double *distance1, double *distance2, double *criterion,
+                   double *times, double *mses, int *numA, int *numAt, int *n_outer, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_TRY(check_common(ctx, "CSALSA_v2", y, taps, opts, x_init, M, N, batch, taille));
+    if (!mu1 || !mu2 || !sigma) return fail(ctx, SBTV_ERR_BADARG, "CSALSA_v2: missing required argument");
+    for (int b = 0; b < batch; ++b)
+        if (!(mu1[b] > 0.0) || !(mu2[b] > 0.0))
+            return fail(ctx, SBTV_ERR_MISSING_LS, "(A^T A + mu I)^(-1) must be specified: mu1, mu2 must be > 0");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    { FftPlan chk; SBTV_TRY(fft_plan(ctx, M, N, 1, &chk)); }
+    const size_t P = (size_t)M * N, cnt = P * batch;
+    const double *yd = nullptr, *td = nullptr, *xi = nullptr;
+    SBTV_TRY(stage_in(ctx, "admm.in.y", y, cnt, flags, &yd));
+    SBTV_TRY(stage_in(ctx, "admm.in.true", true_x, cnt, flags, &td));
+    SBTV_TRY(stage_in(ctx, "admm.in.xinit", x_init, cnt, flags, &xi));
+    double *xo = nullptr;
+    SBTV_TRY(stage_out_buf(ctx, "admm.out.x", x_out, cnt, flags, &xo));
+    const int mi = opts->maxiter;
+    for (int b = 0; b < batch; ++b) {
+        const size_t o = (size_t)b * P, r = (size_t)b * mi;
+        SBTV_TRY(csalsa_one(ctx, yd + o, M, N, taps + (size_t)b * taille * taille, taille, mu1[b], mu2[b], sigma[b],
+                            epsilon ? epsilon[b] : 0.0, continuationfactor, opts, td ? td + o : nullptr,
+                            xi ? xi + o : nullptr, xo + o, objective ? objective + r : nullptr,
+                            distance1 ? distance1 + r : nullptr, distance2 ? distance2 + r : nullptr,
+                            criterion ? criterion + r : nullptr, times ? times + r : nullptr, mses ? mses + r : nullptr,
+                            numA ? numA + b : nullptr, numAt ? numAt + b : nullptr, n_outer ? n_outer + b : nullptr));
+    }
+    SBTV_TRY(stage_out_copy(ctx, x_out, xo, cnt, flags));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const double *taps, int taille,
+                  const double *tau1, const double *tau2, const double *mu1, const double *mu2, const double *mu_ls,
+                  int TViters2, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init, double *x_out,
+                  double *objective, double *distance, double *times, double *mses, int *numA, int *numAt, int *n_outer,
+                  int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_TRY(check_common(ctx, "CoRAL_v2", y, taps, opts, x_init, M, N, batch, taille));
+    if (!tau1 || !tau2 || !mu1 || !mu2) return fail(ctx, SBTV_ERR_BADARG, "CoRAL_v2: missing required argument");
+    if (TViters2 <= 0) return fail(ctx, SBTV_ERR_MAXITER, "CoRAL_v2: TViters2 must be positive");
+    for (int b = 0; b < batch; ++b)
+        if (!(mu1[b] > 0.0) || !(mu2[b] > 0.0) || (mu_ls && !(mu_ls[b] > 0.0)))
+            return fail(ctx, SBTV_ERR_MISSING_LS, "(A^T A + mu I)^(-1) must be specified: mu1, mu2 must be > 0");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    { FftPlan chk; SBTV_TRY(fft_plan(ctx, M, N, 1, &chk)); }
+    const size_t P = (size_t)M * N, cnt = P * batch;
+    const double *yd = nullptr, *td = nullptr, *xi = nullptr;
+    SBTV_TRY(stage_in(ctx, "admm.in.y", y, cnt, flags, &yd));
+    SBTV_TRY(stage_in(ctx, "admm.in.true", true_x, cnt, flags, &td));
+    SBTV_TRY(stage_in(ctx, "admm.in.xinit", x_init, cnt, flags, &xi));
+    double *xo = nullptr;
+    SBTV_TRY(stage_out_buf(ctx, "admm.out.x", x_out, cnt, flags, &xo));
+    const int mi = opts->maxiter;
+    for (int b = 0; b < batch; ++b) {
+        const size_t o = (size_t)b * P;
+        SBTV_TRY(coral_one(ctx, yd + o, M, N, taps + (size_t)b * taille * taille, taille, tau1[b], tau2[b], mu1[b], mu2[b],
+                           mu_ls ? mu_ls[b] : mu1[b] + mu2[b], TViters2, opts, td ? td + o : nullptr,
+                           xi ? xi + o : nullptr, xo + o, objective ? objective + (size_t)b * (mi + 1) : nullptr,
+                           distance ? distance + (size_t)b * mi * 2 : nullptr, times ? times + (size_t)b * (mi + 1) : nullptr,
+                           mses ? mses + (size_t)b * (mi + 1) : nullptr, numA ? numA + b : nullptr,
+                           numAt ? numAt + b : nullptr, n_outer ? n_outer + b : nullptr));
+    }
+    SBTV_TRY(stage_out_copy(ctx, x_out, xo, cnt, flags));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -112,7 +112,7 @@ struct ProxPlan {
     double *partials;             // [batch][nblk]
     unsigned *counters;           // [batch] arrival tickets (in-kernel stop-rule path)
 };
-int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan);
+int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan, const char *tag = "prox");
 // (Re)initialise the control blocks: k=0, done=0 and the per-image lambda from a
 // DEVICE array `lambda_dev` scaled by `lambda_scale`; keep_cur keeps the
 // ping-pong index (warm start from the duals of the previous call).

@@ -510,7 +510,7 @@ __global__ void copy_duals_kernel(double *__restrict__ dst0, double *__restrict_
 
 static inline bool vec_ok(const void *p, int M) { return (M % 2 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
 
-int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl) {
+int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *tag) {
     pl->M = M;
     pl->N = N;
     pl->batch = batch;
@@ -555,11 +555,12 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl) {
     const size_t P = (size_t)M * N;
     size_t npart = (size_t)batch * pl->nblk;
     if ((size_t)batch * FH * pl->fnblk > npart) npart = (size_t)batch * FH * pl->fnblk;
-    SBTV_TRY(ws_get_t(ctx, "prox.ctrl", (size_t)batch, &pl->ctrl));
-    SBTV_TRY(ws_get_t(ctx, "prox.pbuf", 4 * P * batch, &pl->pbuf));
-    SBTV_TRY(ws_get_t(ctx, "prox.partials", npart, &pl->partials));
+    const std::string t(tag ? tag : "prox");          // a second concurrent prox (CoRAL) needs its own state
+    SBTV_TRY(ws_get_t(ctx, (t + ".ctrl").c_str(), (size_t)batch, &pl->ctrl));
+    SBTV_TRY(ws_get_t(ctx, (t + ".pbuf").c_str(), 4 * P * batch, &pl->pbuf));
+    SBTV_TRY(ws_get_t(ctx, (t + ".partials").c_str(), npart, &pl->partials));
     // arrival tickets of the in-kernel control path: zero between launches (the last workgroup resets it)
-    SBTV_TRY(ws_get_t(ctx, "prox.counters", (size_t)batch, &pl->counters));
+    SBTV_TRY(ws_get_t(ctx, (t + ".counters").c_str(), (size_t)batch, &pl->counters));
     SBTV_HIP(ctx, hipMemsetAsync(pl->counters, 0, sizeof(unsigned) * batch, ctx->stream));
     return 0;
 }

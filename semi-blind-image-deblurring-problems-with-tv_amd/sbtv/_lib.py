@@ -81,6 +81,10 @@ SIGNATURES = {
     "sbtv_salsa_opts_default": (None, [C.POINTER(sbtv_salsa_opts)]),
     "sbtv_SALSA_v2": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.POINTER(sbtv_salsa_opts), _P, _P, _P, _P, _P, _P,
                            _P, _P, _P, _P, _I]),
+    "sbtv_CSALSA_v2": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _D, C.POINTER(sbtv_salsa_opts), _P, _P, _P,
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "sbtv_CoRAL_v2": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, C.POINTER(sbtv_salsa_opts), _P, _P, _P,
+                           _P, _P, _P, _P, _P, _P, _P, _I]),
     "sbtv_fista_tv": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _D, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P, _I]),
     "sbtv_SAPG_algorithm": (_I, [_P, _P, _I, _I, _I, C.POINTER(sbtv_sapg_opts), _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _P, _P, ALLREDUCE_FN, _P, _I]),
