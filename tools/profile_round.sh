@@ -1,0 +1,33 @@
+#!/bin/bash
+# Reproduce the numbers committed under profiles/ (run on the GPU box from the repo root):
+#   bash tools/profile_round.sh r01_v5
+# 1. plain bench line                      -> profiles/<tag>_bench.json
+# 2. rocprofv3 --kernel-trace --stats      -> profiles/<tag>_kernel_stats.csv
+# 3. three separate --pmc passes (SQ activity / FETCH_SIZE / WRITE_SIZE; never combined with tracing)
+#                                          -> profiles/<tag>_pmc.json, profiles/r01_pmc_chambolle.json
+set -eo pipefail
+TAG=${1:?tag}
+R=$PWD
+O=$R/gpurun_out/prof_$TAG
+rm -rf "$O"; mkdir -p "$O"
+export TMPDIR=/tmp
+python3 bench.py --steps 200 --warmup 20 > "$O/bench.json" 2> "$O/bench.err"
+cp "$O/bench.json" "$R/gpurun_out/${TAG}_bench.json"
+echo "bench done"; tail -c 600 "$O/bench.json"; echo
+cd /tmp
+B="$R/bench.py --steps 30 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 $B > "$O/stats.log" 2>&1
+echo "kernel trace done"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+          --output-format csv -d "$O/pmc_sq" -- python3 $B > "$O/pmc_sq.log" 2>&1
+echo "pmc sq done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 $B > "$O/pmc_fetch.log" 2>&1
+echo "pmc fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 $B > "$O/pmc_write.log" 2>&1
+echo "pmc write done"
+cd "$R"
+python3 tools/summarize_profiles.py "$TAG" "$O/stats" "$O/pmc_sq" "$O/pmc_fetch" "$O/pmc_write"
+mkdir -p gpurun_out/profiles_$TAG
+cp profiles/${TAG}_* profiles/r01_pmc_chambolle.json gpurun_out/profiles_$TAG/
+# the raw traces are large: keep only the summaries in gpurun_out
+rm -rf "$O/stats" "$O/pmc_sq" "$O/pmc_fetch" "$O/pmc_write"
