@@ -263,8 +263,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         SBTV_HIP(ctx, hipEventCreate(&ev_p0[s]));
         SBTV_HIP(ctx, hipEventCreate(&ev_p1[s]));
     }
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
     auto destroy_events = [&]() {
         for (int s = 0; s < 2; ++s) {
+            if (gexec[s]) (void)hipGraphExecDestroy(gexec[s]);
             (void)hipEventDestroy(ev_done[s]);
             (void)hipEventDestroy(ev_p0[s]);
             (void)hipEventDestroy(ev_p1[s]);
@@ -273,16 +275,19 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const auto t0 = std::chrono::steady_clock::now();
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
 
-    // enqueue outer iteration `outer` (reads x = xbuf[(outer-1)&1] through g, writes xbuf[outer&1])
-    auto enqueue = [&](int outer) -> int {
+    // enqueue the kernels of outer iteration `outer` (reads x = xbuf[(outer-1)&1] through g, writes
+    // xbuf[outer&1]); `timed` brackets the prox with events (not inside a graph capture)
+    bool prox_timed[2] = {false, false};
+    auto enqueue_body = [&](int outer, bool timed) -> int {
         const int slot = outer & 1;
         double *xn = xbuf[slot];
         const double *xprev = xbuf[slot ^ 1];
         // (1) TV prox with warm-started duals (:429); the control block was re-armed by the previous
         //     iteration's collector (or by prox_reset before the loop)
-        SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
+        if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
         SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u));     // u = g - lambda div p written by the last launch
-        SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
+        if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
+        prox_timed[slot] = timed;
         // (2) LS step in the spectral domain + residual energy (:434-444)
         RowsArgs a{};
         a.dir_fwd = 1;
@@ -310,6 +315,28 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         // they are visible to the host once ev_done has completed
         hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, pp.ctrl,
                            scal_hd + (size_t)slot * batch, (const int *)frozen_d, 1);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    // Small problems are launch-bound (about a dozen kernels of a few microseconds): from the third outer
+    // iteration on, the body of each x-buffer slot is captured once and replayed with one hipGraphLaunch.
+    bool use_graph = graph_wanted(cnt);
+    auto enqueue = [&](int outer) -> int {
+        const int slot = outer & 1;
+        if (use_graph && outer >= 3) {
+            if (!gexec[slot]) {
+                if (graph_begin(ctx) != 0 || graph_end(ctx, enqueue_body(outer, false), &gexec[slot]) != 0) {
+                    use_graph = false;                    // capture unavailable: keep launching eagerly
+                    gexec[slot] = nullptr;
+                }
+            }
+            if (gexec[slot]) {
+                SBTV_HIP(ctx, hipGraphLaunch(gexec[slot], ctx->stream));
+                SBTV_HIP(ctx, hipEventRecord(ev_done[slot], ctx->stream));
+                return 0;
+            }
+        }
+        SBTV_TRY(enqueue_body(outer, true));
         SBTV_HIP(ctx, hipEventRecord(ev_done[slot], ctx->stream));
         return 0;
     };
@@ -317,9 +344,11 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     auto process = [&](int outer) -> int {
         const int slot = outer & 1;
         SBTV_HIP(ctx, hipEventSynchronize(ev_done[slot]));
-        float ms = 0.f;
-        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ev_p0[slot], ev_p1[slot]));
-        ms_prox += ms;
+        if (prox_timed[slot]) {
+            float ms = 0.f;
+            SBTV_HIP(ctx, hipEventElapsedTime(&ms, ev_p0[slot], ev_p1[slot]));
+            ms_prox += ms;
+        }
         const double tnow = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         bool changed = false;
         for (int b = 0; b < batch; ++b) {

@@ -34,8 +34,10 @@ __device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigne
 }
 
 __global__ __launch_bounds__(256) void randn_kernel(double *__restrict__ Z, size_t P, unsigned long long seed,
-                                                    unsigned step, unsigned chain0) {
+                                                    unsigned step, unsigned chain0,
+                                                    const double *__restrict__ step_dev) {
     const unsigned b = blockIdx.y;
+    if (step_dev) step = (unsigned)step_dev[0];      // graph replay: the step counter lives in device memory
     const size_t P2 = P / 2;
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P2; q += (size_t)gridDim.x * 256) {
         unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = step, c3 = chain0 + b;
@@ -371,10 +373,11 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     SBTV_TRY(ws_get_t(ctx, "sapg.Y", spec * nspec, &Ys));
     SBTV_TRY(ws_get_t(ctx, "sapg.S1", (size_t)nspec * P / 2, &S1));
     const size_t t2 = (size_t)taille * taille;
-    double *par = nullptr;       // [taps | d0 | d1] per spectrum set, then lam[batch], sigma2[batch]
-    SBTV_TRY(ws_get_t(ctx, "sapg.par", 3 * t2 * nspec + 2 * (size_t)batch, &par));
+    double *par = nullptr;       // [taps | d0 | d1] per spectrum set, then lam[batch], sigma2[batch], noise step
+    const size_t npar_all = 3 * t2 * nspec + 2 * (size_t)batch + 1;
+    SBTV_TRY(ws_get_t(ctx, "sapg.par", npar_all, &par));
     double *taps_d = par, *d0_d = par + t2 * nspec, *d1_d = par + 2 * t2 * nspec, *lam_d = par + 3 * t2 * nspec,
-           *sig_d = lam_d + batch;
+           *sig_d = lam_d + batch, *step_d = sig_d + batch;
     const int nrb = fft_rows_blocks(fp);
     double *acc = nullptr, *scal_d = nullptr;
     SBTV_TRY(ws_get_t(ctx, "sapg.acc", (size_t)batch * 3 * nrb, &acc));
@@ -382,7 +385,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     double *scal_h = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(double) * (4 * batch + 3 * t2 * nspec + 2 * batch), &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * (4 * batch + 3 * t2 * nspec + 2 * batch + 1), &pz));
         scal_h = static_cast<double *>(pz);
     }
     double *par_h = scal_h + 4 * (size_t)batch;       // pinned staging for the per-iteration parameter upload
@@ -461,7 +464,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_HIP(ctx, hipMemcpyAsync(Z, noise + noise_step * cnt, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
         } else {
             hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed,
-                               (unsigned)noise_step, 0u);
+                               (unsigned)noise_step, 0u, (const double *)nullptr);
             SBTV_HIP(ctx, hipGetLastError());
         }
         ++noise_step;
@@ -471,6 +474,81 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         SBTV_TRY(prox_zero_duals(ctx, pp));
         SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
         SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox));
+        return 0;
+    };
+
+    // ---- hipGraph replay (small images: ~25 launches of a few microseconds per iteration make the loop
+    // launch-bound).  The graph body reads every per-iteration value (taps, lambda*theta, sigma^2, noise step)
+    // from the device parameter block, which its first node refreshes from the pinned staging block.
+    const bool params_move = !(op->fix_p[0] && (npar < 2 || op->fix_p[1]));
+    bool use_graph = (noise == nullptr) && graph_wanted(cnt);
+    hipGraphExec_t g_warm = nullptr, g_main = nullptr;
+    struct GraphGuard {
+        hipGraphExec_t *a, *b;
+        ~GraphGuard() {
+            if (*a) (void)hipGraphExecDestroy(*a);
+            if (*b) (void)hipGraphExecDestroy(*b);
+        }
+    } graph_guard{&g_warm, &g_main};
+    auto graph_body = [&](bool main_loop) -> int {
+        SBTV_HIP(ctx, hipMemcpyAsync(par, par_h, sizeof(double) * npar_all, hipMemcpyHostToDevice, ctx->stream));
+        if (main_loop && params_move) {
+            // spectra of the parameters moved by the previous iteration, then grad = AT(AX - y) with them
+            SBTV_TRY(psf_spectrum(ctx, fps, taps_d, taille, Hs));
+            SBTV_TRY(psf_spectrum(ctx, fps, d0_d, taille, D1s));
+            SBTV_TRY(psf_spectrum(ctx, fps, npar > 1 ? d1_d : d0_d, taille, D2s));
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.dir_inv = 1;
+            a.op = OP_GRADF;
+            a.H = Hs;
+            a.Y = Ys;
+            a.acc = acc;
+            a.shared_spec = shared;
+            SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+            SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+            SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+        }
+        hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed, 0u, 0u,
+                           (const double *)step_d);
+        SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));
+        SBTV_TRY(do_prox());
+        SBTV_TRY(operator_pass(main_loop ? !params_move : true));
+        SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
+        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(double) * 4 * batch, hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    };
+    // host side of one replayed iteration: stage the parameters, launch, wait for the scalars
+    auto graph_iteration = [&](hipGraphExec_t *exec, bool main_loop, const std::vector<double> &th, bool *replayed) -> int {
+        *replayed = false;
+        if (!*exec) {
+            if (graph_begin(ctx) != 0 || graph_end(ctx, graph_body(main_loop), exec) != 0) {
+                *exec = nullptr;
+                use_graph = false;                 // capture unavailable: the caller keeps launching eagerly
+                return 0;
+            }
+        }
+        if (main_loop && params_move) {
+            for (int s = 0; s < nspec; ++s) {
+                double pv[3] = {p0[s], (op->kind == SBTV_PSF_GAUSSIAN || op->kind == SBTV_PSF_MOFFAT) ? p1[s] : 0.0,
+                                op->kind == SBTV_PSF_GAUSSIAN ? op->phi : 0.0};
+                int rc = sbtv_psf_taps(op->kind, taille, pv, par_h + s * t2, par_h + t2 * nspec + s * t2,
+                                       par_h + 2 * t2 * nspec + s * t2);
+                if (rc != 0) return fail(ctx, rc, "SAPG_algorithm: PSF parameters out of range");
+                last_p0[s] = p0[s];
+                last_p1[s] = p1[s];
+            }
+        }
+        double *stage = par_h + 3 * t2 * nspec;
+        for (int b = 0; b < batch; ++b) {
+            stage[b] = lamb * th[b];
+            stage[batch + b] = sig2[b];
+        }
+        stage[2 * batch] = (double)noise_step;
+        ++noise_step;
+        SBTV_HIP(ctx, hipGraphLaunch(*exec, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *replayed = true;
         return 0;
     };
 
@@ -504,12 +582,16 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         SBTV_TRY(do_prox());
         SBTV_TRY(operator_pass(true));                       // grad for the first step
         for (int ii = 2; ii <= warmup; ++ii) {
-            SBTV_TRY(next_noise());
-            SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));        // :80-81
-            SBTV_TRY(do_prox());                                                               // :82
-            SBTV_TRY(operator_pass(true));
-            SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
-            SBTV_TRY(fetch_scalars());
+            bool replayed = false;
+            if (use_graph && ii >= 3) SBTV_TRY(graph_iteration(&g_warm, false, theta, &replayed));
+            if (!replayed) {
+                SBTV_TRY(next_noise());
+                SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));        // :80-81
+                SBTV_TRY(do_prox());                                                               // :82
+                SBTV_TRY(operator_pass(true));
+                SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
+                SBTV_TRY(fetch_scalars());
+            }
             if (logpi_wu)
                 for (int b = 0; b < batch; ++b) logpi_wu[(size_t)b * warmup + (ii - 1)] = log_pi(b, theta[b], sig2[b]);   // :85
         }
@@ -534,12 +616,13 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     }
     SBTV_TRY(upload_lam_sigma(theta));
     SBTV_TRY(do_prox());                                      // proxGX = proxG(X, thetas(1))   (:134)
-    const bool params_move = !(op->fix_p[0] && (npar < 2 || op->fix_p[1]));
     for (int ii = 2; ii <= samples; ++ii) {
         const int i0 = ii - 1;
+        bool replayed = false;
+        if (use_graph && ii >= 3) SBTV_TRY(graph_iteration(&g_main, true, theta, &replayed));
         // gradF(X, p(ii-1), sigma(ii-1)): `grad` already holds AT(AX-y) for the current spectra unless
         // the PSF parameters moved at the end of the previous iteration
-        if (params_move && ii > 2) {
+        if (!replayed && params_move && ii > 2) {
             SBTV_TRY(refresh_spectra());
             RowsArgs a{};
             a.dir_fwd = 1;
@@ -553,13 +636,15 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
             SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         }
-        SBTV_TRY(upload_lam_sigma(theta));                                                    // theta(ii-1), sigma(ii-1)
-        SBTV_TRY(next_noise());
-        SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));             // :160-161
-        SBTV_TRY(do_prox());                                                                   // :162
-        SBTV_TRY(operator_pass(!params_move));                                                 // G_w*, G_s, f  (:170-188)
-        SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));                // g(X)          (:165)
-        SBTV_TRY(fetch_scalars());
+        if (!replayed) {
+            SBTV_TRY(upload_lam_sigma(theta));                                                    // theta(ii-1), sigma(ii-1)
+            SBTV_TRY(next_noise());
+            SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));             // :160-161
+            SBTV_TRY(do_prox());                                                                   // :162
+            SBTV_TRY(operator_pass(!params_move));                                                 // G_w*, G_s, f  (:170-188)
+            SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));                // g(X)          (:165)
+            SBTV_TRY(fetch_scalars());
+        }
         const double delta = op->d_scale * (pow((double)ii, -op->d_exp) / dimX);              // :55
         // per-chain gradients
         std::vector<double> Gt(batch), Gp0(batch), Gp1(batch), Gs(batch);

@@ -102,6 +102,11 @@ int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int
 int stage_out_buf(sbtv_ctx *ctx, const char *name, double *p, size_t count, int flags, double **dev);
 int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count, int flags);
 
+// hipGraph replay of launch-bound iteration bodies (ctx.hip)
+bool graph_wanted(size_t total_px);
+int graph_begin(sbtv_ctx *ctx);
+int graph_end(sbtv_ctx *ctx, int body_rc, hipGraphExec_t *exec);
+
 // ----------------------------- TV kernels (tv.hip) --------------------------
 struct ProxPlan {
     int M, N, batch;

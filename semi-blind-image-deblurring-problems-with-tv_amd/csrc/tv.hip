@@ -609,9 +609,13 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         const dim3 fgrid(pl.fnblk, 1, pl.batch);   // linear tile list, remapped per XCD inside the kernel
         const int nl = (maxiter + FHJ - 1) / FHJ;
         const int base = maxiter / nl, extra = maxiter % nl;
-        // SBTV_INLINE_CTRL=1: the last workgroup of a normal launch applies the stop rule itself instead of
-        // a separate control kernel.  Measured gain on MI355X: +0.6 % SALSA it/s, so it stays opt-in.
-        static const bool env_inline = (getenv("SBTV_INLINE_CTRL") != nullptr);
+        // In-kernel stop rule: the last workgroup of a normal launch applies the rule itself instead of a separate
+        // control kernel.  On large grids the gain is marginal (+0.6 % SALSA it/s at 2048^2), so there it needs
+        // SBTV_INLINE_CTRL=1; grids below one round of workgroups (e.g. 512^2: 125 tiles) are bound by the chain
+        // of dependent launches and gain ~6 % per SAPG iteration, so they take it by default (SBTV_INLINE_CTRL=0
+        // switches it off).
+        static const char *env_inl = getenv("SBTV_INLINE_CTRL");
+        const bool env_inline = env_inl ? (env_inl[0] != '0') : ((size_t)pl.fnblk * pl.batch <= 512);
         auto launch_fused = [&](int steps, int redo, int write_f) {
             bool launched = false;
             const int inl = (!redo && env_inline) ? 1 : 0;

@@ -47,6 +47,9 @@ def test_exact_fast_single_step_and_tile_variants_agree(tmp_path):
         "tile_8_4": {"SBTV_FUSED_VARIANT": "8,4,2"},        # other tile geometry of the fused kernel
         "tile_16_4": {"SBTV_FUSED_VARIANT": "16,4,1"},
         "nospec": {"SBTV_FUSED_VARIANT": "4,8,2"},
+        "rows1": {"SBTV_FUSED_VARIANT": "4,8,4,1"},         # one row per lane (64-row tiles)
+        "inline": {"SBTV_INLINE_CTRL": "1"},                # stop rule applied by the last workgroup of a launch
+        "separate": {"SBTV_INLINE_CTRL": "0"},              # ... or always by the separate control kernel
     }
     for name, env in variants.items():
         got = _run(tmp_path, name, env)
@@ -57,3 +60,58 @@ def test_exact_fast_single_step_and_tile_variants_agree(tmp_path):
         assert len(got["obj"]) == len(ref["obj"]), name      # same SALSA stopping iteration
         np.testing.assert_allclose(got["obj"], ref["obj"], rtol=1e-10, err_msg=name)
         assert np.max(np.abs(got["x"] - ref["x"])) < 1e-8, name
+
+
+GRAPH_CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "semi-blind-image-deblurring-problems-with-tv_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import sbtv
+from conftest import synth_image
+x = synth_image(128, 128, 6)
+res = {}
+for kind, p, names in (("gaussian", (0.4, 0.3), ("w1", "w2")), ("moffat", (0.4, 3.5), ("alpha", "beta"))):
+    st = sbtv.demo_setup(kind, x, np.random.default_rng(1).standard_normal(x.shape), evMax=1.0)
+    if kind == "gaussian":
+        A = sbtv.BlurOperator(sbtv.psf_family(kind, 7, p)[0])
+        mu = 0.003
+        for crit in (1, 2):
+            out = sbtv.SALSA_v2(st["y"], A, 0.03 * st["sigma"] ** 2, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", x,
+                                "StopCriterion", crit, "ToleranceA", 1e-5 if crit == 1 else 1e-4, "MAXITERA", 80,
+                                "TVINITIALIZATION", 1, "TViters", 10)
+            res["salsa_x%%d" %% crit], res["salsa_obj%%d" %% crit], res["salsa_mse%%d" %% crit] = out[0], out[3], out[6]
+    # SAPG with the device Philox stream: PSF parameters fixed (gaussian demo) and estimated (moffat demo)
+    op = dict(samples=40, warmup=12, burnIn=20, psf_size=7, phi=0.0, gamma=st["gamma"], th_init=0.01, min_th=1e-3,
+              max_th=1.0, sigma=st["sigma"], sigma_init=st["sigma_init"], sigma_min=st["sigma_min"],
+              sigma_max=st["sigma_max"], d_scale=1.0, d_exp=0.8, fix_sigma=0, seed=7)
+    op["lambda"] = st["lambda"]
+    fix = kind == "gaussian"
+    for q, nm in enumerate(names):
+        op[nm] = p[q]
+        op[nm + "_init"] = p[q] if fix else (1.0, 10.0)[q]
+        op["min_" + nm], op["max_" + nm], op["fix_" + nm] = (0.1, 0.1)[q] if fix else (1e-2, 0.1)[q], (1.0, 10.0)[q], int(fix)
+    c = dict(theta=0.01, w1=10.0, w2=10.0, alpha=10.0, beta=1e4, sigma=1000.0, lam=1.0, gam=1.0)
+    fn = sbtv.SAPG_algorithm_Guassian if fix else sbtv.SAPG_algorithm_moffat
+    r = fn(st["y"], op, c)[-1]
+    for key in ("thetas", "sigmas", "logPiTraceX", "logPiTrace_WU", names[0] + "s", names[1] + "s", "Xlast_sample"):
+        res[kind + "_" + key] = np.asarray(r[key])
+np.savez(sys.argv[1], **res)
+"""
+
+
+def test_graph_replay_is_bit_identical_to_eager_launches(tmp_path):
+    """Small problems replay a captured hipGraph per iteration (SALSA_v2, SAPG warm-up and main loop); the
+    kernels and their order are the same, so every trace must be bit-identical to eager launching."""
+    outs = {}
+    for name, env in (("eager", {"SBTV_GRAPH": "0"}), ("graph", {"SBTV_GRAPH": "1"}), ("default", {})):
+        out = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.pop("SBTV_GRAPH", None)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", GRAPH_CHILD % {"root": ROOT}, out], check=True, env=e, timeout=600)
+        outs[name] = np.load(out)
+    for name in ("graph", "default"):
+        for key in outs["eager"].files:
+            np.testing.assert_array_equal(outs[name][key], outs["eager"][key], err_msg=f"{name}:{key}")
+    assert len(outs["eager"]["salsa_obj1"]) > 10 and outs["eager"]["moffat_alphas"][-1] != outs["eager"]["moffat_alphas"][0]
