@@ -29,7 +29,24 @@ import time
 import numpy as np
 import scipy.fft as _sfft
 
-_WORKERS = max(1, os.cpu_count() or 1)
+def _host_cores() -> int:
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota if one is set
+    (a container that sees 256 CPUs but owns a 16-core share would otherwise oversubscribe the FFT pool)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+_WORKERS = _host_cores()
 
 
 def set_workers(n: int) -> None:

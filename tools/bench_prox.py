@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "semi-blind-image-deblurring-problems-with
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--cols", type=int, default=0, help="columns N (default: size)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--reps", type=int, default=50)
@@ -29,7 +30,8 @@ def main():
     rng = np.random.default_rng(0)
     man = np.load(os.path.join(ROOT, "tests", "golden", "man_512.npy")).astype(np.float64)
     r = max(1, a.size // 512)
-    img = np.tile(man, (r, r))[:a.size, :a.size]
+    ncols = a.cols or a.size
+    img = np.tile(man, (r, r))[:a.size, :ncols]
     g = np.stack([img + rng.standard_normal(img.shape) for _ in range(a.batch)])
     gd = sbtv.to_device(g)
     lam = 10.0
@@ -40,11 +42,11 @@ def main():
         f, px, py = sbtv.chambolle_prox_TV_stop(gd, "lambda", lam, "maxiter", a.iters, "dualvars", (px, py))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
-    P = a.size * a.size * a.batch
+    P = a.size * ncols * a.batch
     byts = (40 * a.iters + 32) * P
     print(f"variant={os.environ.get('SBTV_FUSED_VARIANT', 'default')} single={os.environ.get('SBTV_SINGLE_STEP', '0')} "
-          f"size={a.size} batch={a.batch} K={a.iters}: {dt * 1e3:.3f} ms/prox (incl. python + copies), "
-          f"{dt * 1e6 / a.iters:.1f} us/iter, {byts / dt / 1e9:.0f} GB/s algorithmic")
+          f"size={a.size}x{ncols} batch={a.batch} K={a.iters}: {dt * 1e3:.3f} ms/prox (incl. python + copies), "
+          f"{dt * 1e6 / a.iters:.1f} us/iter, {dt * 1e12 / a.iters / P:.2f} ps/pixel/iter, {byts / dt / 1e9:.0f} GB/s algorithmic")
 
 
 if __name__ == "__main__":
