@@ -11,7 +11,7 @@ from .operators import (BlurOperator, A_wrapper, Gaussian_psf, psf_gaussian, psf
                         rfft2_packed, unpack_half_spectrum)
 from .salsa import SALSA_v2
 from .admm import csalsa, CSALSA_v2, CoRAL, CoRAL_v2
-from .diagnostics import ssim, save_results, load_results
+from .diagnostics import ssim, save_results, load_results, plot_traces, save_image
 from .metrics import PSNR, MSE
 from .fista import my_fista, my_deblur_fista, Psi_TV
 from .sapg import (SAPG_algorithm_Guassian, SAPG_algorithm_moffat, SAPG_algorithm_laplace, max_eigenval,
@@ -23,5 +23,5 @@ __all__ = [
     "Context", "SbtvError", "default_context", "load_library", "to_device", "to_host", "LIB_PATH",
     "chambolle_prox_TV_stop", "TVnorm", "BlurOperator", "A_wrapper", "Gaussian_psf", "psf_gaussian",
     "psf_moffat", "psf_laplace", "psf_family", "rfft2_packed", "unpack_half_spectrum", "SALSA_v2", "PSNR", "MSE",
-    "csalsa", "CSALSA_v2", "CoRAL", "CoRAL_v2", "ssim", "save_results", "load_results",
+    "csalsa", "CSALSA_v2", "CoRAL", "CoRAL_v2", "ssim", "save_results", "load_results", "plot_traces", "save_image",
 ]

@@ -62,3 +62,60 @@ def save_results(path, results, **extra):
 def load_results(path):
     with np.load(path, allow_pickle=False) as z:
         return {k: (z[k].item() if z[k].ndim == 0 else z[k]) for k in z.files}
+
+
+# ---- figures of the demos (run_Gaussian_demo.m:247-301) without a plotting library -------------------------
+def _polyline(vals, x0, y0, w, h, lo, hi, n_max=2000):
+    v = np.asarray(vals, dtype=np.float64)
+    if v.size > n_max:                                       # decimate long traces for the picture only
+        v = v[np.linspace(0, v.size - 1, n_max).astype(int)]
+    xs = x0 + w * (np.arange(v.size) / max(v.size - 1, 1))
+    ys = y0 + h - h * (v - lo) / (hi - lo if hi > lo else 1.0)
+    return " ".join(f"{a:.1f},{b:.1f}" for a, b in zip(xs, ys))
+
+
+def plot_traces(path, results, true_values=None, names=None):
+    """One panel per trace of a SAPG `results` dict (thetas, <param>s, sigmas) with the EB estimate in the title and
+    the true value as a red line, like the demo's figSigma / figTheta / figw1 / figw2; written as a plain SVG."""
+    true_values = true_values or {}
+    if names is None:
+        names = [k for k in ("thetas", "w1s", "w2s", "alphas", "betas", "bs", "sigmas") if k in results]
+    W, H, pad = 420, 240, 48
+    parts = [f'<svg xmlns="http://www.w3.org/2000/svg" width="{W * len(names)}" height="{H}" font-family="sans-serif" '
+             f'font-size="11">', f'<rect width="{W * len(names)}" height="{H}" fill="white"/>']
+    for i, nm in enumerate(names):
+        v = np.asarray(results[nm], dtype=np.float64)
+        tv = true_values.get(nm)
+        lo, hi = float(v.min()), float(v.max())
+        if tv is not None:
+            lo, hi = min(lo, tv), max(hi, tv)
+        if hi <= lo:
+            hi = lo + 1.0
+        x0, y0, w, h = i * W + pad, 24, W - pad - 12, H - 24 - 36
+        eb = results.get(nm[:-1] + "_EB")
+        title = nm[:-1] + "_n" + (f"   (EB estimate {eb:.5g})" if eb is not None else "")
+        parts.append(f'<rect x="{x0}" y="{y0}" width="{w}" height="{h}" fill="none" stroke="#888"/>')
+        parts.append(f'<text x="{x0}" y="16">{title}</text>')
+        parts.append(f'<text x="{x0 - 4}" y="{y0 + 10}" text-anchor="end">{hi:.4g}</text>')
+        parts.append(f'<text x="{x0 - 4}" y="{y0 + h}" text-anchor="end">{lo:.4g}</text>')
+        parts.append(f'<text x="{x0 + w / 2}" y="{y0 + h + 26}" text-anchor="middle">Iteration (n), 1..{v.size}</text>')
+        if tv is not None:
+            yt = y0 + h - h * (tv - lo) / (hi - lo)
+            parts.append(f'<line x1="{x0}" y1="{yt:.1f}" x2="{x0 + w}" y2="{yt:.1f}" stroke="red"/>')
+        parts.append(f'<polyline fill="none" stroke="blue" stroke-width="1.5" points="{_polyline(v, x0, y0, w, h, lo, hi)}"/>')
+    parts.append("</svg>")
+    with open(path, "w") as f:
+        f.write("\n".join(parts))
+    return path
+
+
+def save_image(path, x, vmin=None, vmax=None):
+    """`imagesc(x), colormap gray` as a binary PGM (readable by any image viewer); scaled to [vmin, vmax]."""
+    a = np.asarray(x, dtype=np.float64)
+    lo = float(a.min()) if vmin is None else vmin
+    hi = float(a.max()) if vmax is None else vmax
+    g = np.clip(np.rint(255 * (a - lo) / (hi - lo if hi > lo else 1.0)), 0, 255).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (g.shape[1], g.shape[0]))
+        f.write(g.tobytes())
+    return path

@@ -128,3 +128,17 @@ def test_results_round_trip(tmp_path):
     np.testing.assert_array_equal(back["thetas"], res["thetas"])
     np.testing.assert_array_equal(back["xMAP"], res["xMAP"])
     assert "options" not in back
+
+
+def test_trace_plot_and_image_files(tmp_path):
+    d = _diagnostics()
+    res = dict(thetas=0.01 + 0.03 * (1 - np.exp(-np.arange(5000) / 800.0)), theta_EB=0.0398,
+               w1s=np.full(5000, 0.4), w1_EB=0.4, sigmas=np.linspace(2.5, 1.9, 5000), sigma_EB=1.93)
+    p = d.plot_traces(str(tmp_path / "traces.svg"), res, true_values=dict(w1s=0.4, sigmas=1.9776))
+    txt = open(p).read()
+    assert txt.startswith("<svg") and txt.count("<polyline") == 3 and txt.count('stroke="red"') == 2
+    assert "EB estimate 0.0398" in txt
+    img = np.arange(12.0).reshape(3, 4)
+    q = d.save_image(str(tmp_path / "x.pgm"), img)
+    raw = open(q, "rb").read()
+    assert raw.startswith(b"P5\n4 3\n255\n") and raw[-1] == 255 and raw[len(b"P5\n4 3\n255\n")] == 0

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--samples", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=15000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default="", help="directory for the results .npz, the trace figure (SVG) and the images (PGM)")
     a = ap.parse_args()
     d = DEMO[a.kind]
     x = np.load(a.image).astype(np.float64)
@@ -85,7 +86,18 @@ def main():
     xm = sbtv.to_host(xMAP)
     print(f"SALSA_v2: {len(obj) - 1} outer iterations in {1e3 * t_salsa:.1f} ms, calls = {ctx.calls}, "
           f"mse = {sbtv.MSE(x, xm):.3f} dB, PSNR = {sbtv.PSNR(x, xm):.3f} dB "
-          f"(observation: {sbtv.PSNR(x, st['y']):.3f} dB)")
+          f"(observation: {sbtv.PSNR(x, st['y']):.3f} dB), ssim = {sbtv.ssim(x, xm):.4f}")
+    if a.out:
+        # results file + the demo's figures (run_Gaussian_demo.m:247-301): parameter traces, x, y, xMAP
+        os.makedirs(a.out, exist_ok=True)
+        sbtv.save_results(os.path.join(a.out, f"{a.kind}_results.npz"), res, xMAP=xm, objective=obj, mses=mses,
+                          psnr=sbtv.PSNR(x, xm), ssim=sbtv.ssim(x, xm))
+        true = {nm + "s": t for nm, t in zip(d["names"], d["true"])}
+        true["sigmas"] = st["sigma"] ** 2
+        sbtv.plot_traces(os.path.join(a.out, f"{a.kind}_traces.svg"), res, true_values=true)
+        for nm, img in (("x", x), ("y", st["y"]), ("xMAP", xm)):
+            sbtv.save_image(os.path.join(a.out, f"{a.kind}_{nm}.pgm"), img, 0.0, 255.0)
+        print("wrote results, traces and images to", a.out)
 
 
 if __name__ == "__main__":
