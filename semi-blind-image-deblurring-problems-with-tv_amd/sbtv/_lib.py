@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsbtv.so")
+# SBTV_LIBRARY selects another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("SBTV_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libsbtv.so")
 
 SBTV_HOST_PTRS = 0
 SBTV_DEVICE_PTRS = 1
