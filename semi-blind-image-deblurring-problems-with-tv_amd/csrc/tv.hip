@@ -307,7 +307,7 @@ __device__ __forceinline__ void fused_apply_stop_rule(ProxCtrl *c, const double 
 // that draws the last ticket: agent-scope acquire -> barrier -> plain loads of all partials.
 __device__ __forceinline__ void fused_inline_ctrl(ProxCtrl *__restrict__ c, const double *__restrict__ partials_b,
                                                   int nblk, int nsteps, int write_f,
-                                                  unsigned *__restrict__ counter_b) {
+                                                  unsigned *__restrict__ counter_b, int redo_mode) {
     __shared__ double ic_tots[FH];
     __shared__ int ic_last;
     // The partials were stored write-through (`sc1`, fused_store_partial) so no release fence (an L2
@@ -325,6 +325,23 @@ __device__ __forceinline__ void fused_inline_ctrl(ProxCtrl *__restrict__ c, cons
     }
     __syncthreads();
     if (!ic_last) return;
+    if (redo_mode) {
+        // the re-run / finish-only launch that actually had work: book its nsteps iterations (the stop rule is
+        // known to end exactly there) and mark f as valid.  Only the LAST workgroup may do this: an early one
+        // setting f_valid would let late workgroups of the same launch skip their tile.
+        if (nsteps > 0) fused_reduce_steps(partials_b, nblk, nsteps, ic_tots);
+        if (threadIdx.x == 0) {
+            if (nsteps > 0) {
+                c->k += nsteps;
+                c->err = sqrt(ic_tots[nsteps - 1]);
+                c->cur ^= 1;
+                c->redo = 0;
+            }
+            if (write_f) c->f_valid = 1;
+            *counter_b = 0;
+        }
+        return;
+    }
     fused_reduce_steps(partials_b, nblk, nsteps, ic_tots);
     if (threadIdx.x == 0) {
         fused_apply_stop_rule(c, ic_tots, nsteps, write_f);
@@ -667,7 +684,8 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED1_CASE(6, 8, 4)
 #undef SBTV_FUSED1_CASE
             (void)launched;
-            if (!inl)
+            // the re-run launch books its own result (last-workgroup ticket; nothing at all when it is empty)
+            if (!inl && !redo)
                 hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FH), 0, ctx->stream,
                                    pl.ctrl, pl.partials, pl.fnblk, steps, redo, write_f);
         };
