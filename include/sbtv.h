@@ -239,6 +239,9 @@ typedef struct sbtv_sapg_opts {
     double d_scale, d_exp;    /* delta(i) = d_scale * i^-d_exp / dimX                    */
     double c_theta, c_p[2], c_sigma;
     unsigned long long seed;  /* Philox seed when noise == NULL                          */
+    int    chain_offset;      /* index of this call's first chain among ALL chains: chain b draws the
+                                 Philox stream chain_offset + b, so chains spread over several processes
+                                 (sbtv.dist.split_chains) never repeat a stream                     */
 } sbtv_sapg_opts;
 
 /*   y: M*N*batch;  x0: start images (NULL -> y, SAPG_algorithm_Guassian.m:10-12)

@@ -338,6 +338,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     if (op->samples < 2 || op->warmup < 0 || op->burnIn < 1 || op->burnIn > op->samples)
         return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: need samples >= 2, 1 <= burnIn <= samples");
     if (op->chambolleit <= 0) return fail(ctx, SBTV_ERR_MAXITER, "SAPG_algorithm: chambolleit must be positive");
+    if (op->chain_offset < 0) return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: chain_offset must be >= 0");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     const int npar = (op->kind == SBTV_PSF_LAPLACE) ? 1 : 2;
     const int shared = op->share_gradients ? 1 : 0;
@@ -464,7 +465,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_HIP(ctx, hipMemcpyAsync(Z, noise + noise_step * cnt, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
         } else {
             hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed,
-                               (unsigned)noise_step, 0u, (const double *)nullptr);
+                               (unsigned)noise_step, (unsigned)op->chain_offset, (const double *)nullptr);
             SBTV_HIP(ctx, hipGetLastError());
         }
         ++noise_step;
@@ -509,8 +510,8 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
             SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         }
-        hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed, 0u, 0u,
-                           (const double *)step_d);
+        hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed, 0u,
+                           (unsigned)op->chain_offset, (const double *)step_d);
         SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));
         SBTV_TRY(do_prox());
         SBTV_TRY(operator_pass(main_loop ? !params_move : true));

@@ -27,7 +27,7 @@ o.p_init = p_init; o.p_min = p_min; o.p_max = p_max; o.p_true = p_true; o.fix_p 
 o.phi = getf(op,'phi',0);
 o.sigma2_true = op.sigma^2; o.sigma2_init = op.sigma_init; o.sigma2_min = op.sigma_min; o.sigma2_max = op.sigma_max;
 o.d_scale = op.d_scale; o.d_exp = op.d_exp; o.c_theta = c.theta; o.c_sigma = c.sigma;
-o.seed = uint64(getf(op,'seed',1));
+o.seed = uint64(getf(op,'seed',1)); o.chain_offset = int32(getf(op,'chain_offset',0));
 S = double(o.samples); W = max(double(o.warmup),1);
 pth = libpointer('doublePtr', zeros(1,S)); psg = libpointer('doublePtr', zeros(1,S));
 pps = libpointer('doublePtr', zeros(S,2)); plp = libpointer('doublePtr', zeros(1,S));

@@ -50,7 +50,7 @@ class sbtv_sapg_opts(C.Structure):
                 ("sigma2_true", C.c_double),
                 ("d_scale", C.c_double), ("d_exp", C.c_double),
                 ("c_theta", C.c_double), ("c_p", C.c_double * 2), ("c_sigma", C.c_double),
-                ("seed", C.c_ulonglong)]
+                ("seed", C.c_ulonglong), ("chain_offset", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)

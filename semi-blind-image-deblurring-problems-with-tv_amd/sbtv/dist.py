@@ -52,7 +52,8 @@ def shard(n_items, rank=None, world=None):
 
 
 def split_chains(n_chains, rank=None, world=None):
-    """Number of MYULA chains this rank runs and the index of its first chain (for the RNG streams)."""
+    """Number of MYULA chains this rank runs and the index of its first chain: pass them to the SAPG call as
+    op["chains"] and op["chain_offset"] so that chain b draws the Philox stream chain_offset + b."""
     if rank is None or world is None:
         rank, world = rank_world()
     base, extra = divmod(n_chains, world)

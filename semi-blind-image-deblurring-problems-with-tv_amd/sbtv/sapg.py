@@ -114,6 +114,7 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
     o.c_theta = float(c["theta"])
     o.c_sigma = float(c["sigma"])
     o.seed = int(_get(op, "seed", 1))
+    o.chain_offset = int(_get(op, "chain_offset", 0))              # first chain of this process (dist.split_chains)
     S, W = o.samples, max(o.warmup, 1)
     nch = B
     thetas = np.zeros((nch, S)); sigmas = np.zeros((nch, S)); ps = np.zeros((nch, 2, S))

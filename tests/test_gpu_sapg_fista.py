@@ -124,6 +124,63 @@ def test_sapg_shared_gradient_chains_and_philox(ctx):
     # (a direct statistical test of the generator: many samples via a long-ish chain's increments)
 
 
+def test_sapg_chains_split_over_two_processes_match_one_process(ctx):
+    """Multi-GPU data path of config 5 exercised on one GPU: 4 chains in one call (chain streams 0..3) against two
+    concurrent calls of 2 chains each (chain_offset 0 and 2, own context each, as two ranks would run them) whose
+    `reduce_fn` sums the 5 gradient doubles across the two calls the way the RCCL all-reduce does."""
+    import ctypes as C
+    import threading
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    x = synth_image(M, N, 3)
+    st = o.demo_setup("gaussian", x, np.random.default_rng(2).standard_normal((M, N)), evMax=0.99)
+    samples, warmup, burnIn = 10, 4, 5
+    op, c, names = _op_struct("gaussian", st, samples, warmup, burnIn)
+    op["seed"] = 11
+    one = sbtv.SAPG_algorithm_Guassian(st["y"], dict(op, chains=4), c, share_gradients=True)[-1]
+
+    bar = threading.Barrier(2)
+    slots = [None, None]
+    results = [None, None]
+    errors = []
+
+    def make_reduce(r):
+        def reduce_fn(user, buf, n):
+            slots[r] = [buf[q] for q in range(n)]
+            bar.wait(timeout=60)
+            tot = [slots[0][q] + slots[1][q] for q in range(n)]       # fixed order: rank 0 + rank 1
+            bar.wait(timeout=60)
+            for q in range(n):
+                buf[q] = tot[q]
+            return 0
+        return reduce_fn
+
+    def run(r):
+        try:
+            cx = sbtv.Context(0)
+            opr = dict(op, chains=2, chain_offset=2 * r)
+            results[r] = sbtv.SAPG_algorithm_Guassian(st["y"], opr, c, share_gradients=True,
+                                                      reduce_fn=make_reduce(r), ctx=cx)[-1]
+        except Exception as e:                                        # pragma: no cover
+            errors.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    two = results[0] + results[1]                                     # chains 0,1 | 2,3
+    for k in range(4):
+        # same Philox streams -> same samples up to the summation order of the averaged gradients
+        np.testing.assert_allclose(two[k]["thetas"], one[k]["thetas"], rtol=1e-12)
+        np.testing.assert_allclose(two[k]["sigmas"], one[k]["sigmas"], rtol=1e-12)
+        np.testing.assert_allclose(two[k]["Xlast_sample"], one[k]["Xlast_sample"], rtol=1e-9, atol=1e-9)
+    assert np.max(np.abs(two[0]["Xlast_sample"] - two[2]["Xlast_sample"])) > 1e-3    # chains 0 and 2 differ
+
+
 def test_philox_randn_statistics(ctx):
     """K9: the device generator produces standard normals (statistical parity only)."""
     import sbtv
