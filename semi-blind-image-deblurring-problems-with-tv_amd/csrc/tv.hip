@@ -11,6 +11,8 @@
 // per lane and fully coalesced.  u = div p - g/lambda is computed once per
 // pixel (plus a one-row / one-column halo) into LDS, then the forward
 // differences of u are read back from LDS.
+#include <mutex>
+
 #include "sbtv_internal.h"
 
 #pragma clang fp contract(off)
@@ -535,9 +537,9 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     pl->tiles_j = (N + TJ - 1) / TJ;
     pl->nblk = pl->tiles_i * pl->tiles_j;
     {
-        static bool init = false;
-        if (!init) {
-            init = true;
+        // environment hooks are parsed once; contexts may be used from several host threads at the same time
+        static std::once_flag env_once;
+        std::call_once(env_once, [] {
             if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,nw,minw[,rows_per_lane]"
                 int cj = 0, nw = 0, mw = 0, rpl = 2;
                 static const int known[][4] = {{8, 4, 2, 2}, {8, 8, 2, 2}, {8, 8, 1, 2}, {12, 4, 2, 2}, {16, 4, 1, 2},
@@ -561,7 +563,7 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
             }
             // SBTV_EXACT=1: IEEE div/sqrt, no FMA contraction (validation build of the arithmetic)
             if (getenv("SBTV_EXACT") != nullptr) g_fused.fast = 0;
-        }
+        });
     }
     {
         const int core_rows = (g_fused.rpl == 1) ? F1CI : FCI;
