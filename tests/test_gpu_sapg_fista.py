@@ -281,3 +281,68 @@ def test_demo_setup_matches_oracle(ctx):
         for k1, k2 in (("sigma", "sigma"), ("sigma_min", "sigma_min"), ("sigma_max", "sigma_max"), ("Lf", "Lf"),
                        ("lambda", "lam"), ("gamma", "gamma")):
             assert a[k1] == pytest.approx(b[k2], rel=1e-12)
+
+
+def _tiled(man512, size):
+    r = size // 512
+    return np.tile(man512, (r, r))[:size, :size]
+
+
+def _h(v):
+    """host copy of a trace or of a device-resident image"""
+    return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+
+
+def test_sapg_config4_shape_batch_independence_1024(ctx, man512):
+    """configs[3] at its real size (1024^2 Laplace SAPG, a GPU's share of the 64-image batch is 8; 3 here to keep the
+    test short): images of a batch are independent units, so image k of the batched call must reproduce the call on
+    image k alone bit for bit (same kernels, same Philox stream when the chain offset is k)."""
+    import sbtv
+    x = _tiled(man512, 1024)
+    rng = np.random.default_rng(4)
+    sts = [sbtv.demo_setup("laplace", np.clip(x * s + o, 0, 255), rng.standard_normal(x.shape), evMax=0.99)
+           for s, o in ((1.0, 0.0), (0.7, 30.0), (0.5, 90.0))]
+    st = sts[0]
+    op = dict(samples=6, warmup=3, burnIn=3, psf_size=7, gamma=st["gamma"], th_init=0.01, min_th=1e-3, max_th=1.0,
+              sigma=st["sigma"], sigma_init=st["sigma_init"], sigma_min=st["sigma_min"], sigma_max=st["sigma_max"],
+              d_scale=1.0, d_exp=0.8, fix_sigma=0, b=0.3, b_init=0.1, min_b=1e-3, max_b=1.0, fix_b=0, seed=5)
+    op["lambda"] = st["lambda"]
+    ys = sbtv.to_device(np.stack([s["y"] for s in sts]))
+    batched = sbtv.SAPG_algorithm_laplace(ys, op)[-1]
+    assert len(batched) == 3
+    for k in (0, 2):
+        alone = sbtv.SAPG_algorithm_laplace(sbtv.to_device(sts[k]["y"]), dict(op, chain_offset=k))[-1]
+        for key in ("thetas", "bs", "sigmas", "logPiTraceX", "Xlast_sample"):
+            np.testing.assert_array_equal(_h(batched[k][key]), _h(alone[key]), err_msg=f"{k}:{key}")
+    assert not np.array_equal(batched[0]["thetas"], batched[1]["thetas"])
+    for r in batched:
+        assert np.all(np.isfinite(r["logPiTraceX"])) and np.all(_h(r["Xlast_sample"]) >= 0)
+        assert np.all((r["bs"] >= 1e-3) & (r["bs"] <= 1.0)) and r["bs"][-1] != r["bs"][0]
+
+
+def test_sapg_config5_shape_shared_chains_2048(ctx, man512):
+    """configs[4] at its real size: MYULA chains on ONE 2048^2 image (a GPU's share of 32 is 4) with the per-chain
+    PSF-parameter gradients diff_fftgaus_w1/w2 averaged: every chain follows the same parameter trajectory, the
+    samples differ, and the averaged gradient equals the mean of the per-chain gradients of independent runs
+    at the first step (where all runs still share the parameters)."""
+    import sbtv
+    x = _tiled(man512, 2048)
+    st = sbtv.demo_setup("gaussian", x, np.random.default_rng(6).standard_normal(x.shape), evMax=0.99)
+    op = dict(samples=4, warmup=2, burnIn=2, psf_size=7, phi=0.0, gamma=st["gamma"], th_init=0.01, min_th=1e-3,
+              max_th=1.0, sigma=st["sigma"], sigma_init=st["sigma_init"], sigma_min=st["sigma_min"],
+              sigma_max=st["sigma_max"], d_scale=1.0, d_exp=0.8, fix_sigma=0, seed=9,
+              w1=0.4, w1_init=0.5, min_w1=0.1, max_w1=1.0, fix_w1=0, w2=0.3, w2_init=0.35, min_w2=0.1, max_w2=1.0, fix_w2=0)
+    op["lambda"] = st["lambda"]
+    c = dict(theta=0.01, w1=10.0, w2=10.0, sigma=1000.0, lam=1.0, gam=1.0)
+    yd = sbtv.to_device(st["y"])
+    shared = sbtv.SAPG_algorithm_Guassian(yd, dict(op, chains=4), c, share_gradients=True)[-1]
+    assert len(shared) == 4
+    for r in shared[1:]:
+        for key in ("thetas", "w1s", "w2s", "sigmas"):
+            np.testing.assert_array_equal(r[key], shared[0][key])
+    assert np.max(np.abs(_h(shared[0]["Xlast_sample"]) - _h(shared[3]["Xlast_sample"]))) > 1e-3
+    assert shared[0]["w1s"][1] != shared[0]["w1s"][0] and shared[0]["w2s"][1] != shared[0]["w2s"][0]
+    singles = [sbtv.SAPG_algorithm_Guassian(yd, dict(op, chain_offset=k), c)[-1] for k in range(4)]
+    for key in ("grad_theta", "grad_w1", "grad_w2", "grad_sigma"):
+        mean1 = np.mean([s[key][1] for s in singles])
+        assert shared[0][key][1] == pytest.approx(mean1, rel=1e-12), key
