@@ -1,4 +1,5 @@
-// Fused element-wise passes (K4) of the SALSA / FISTA / MYULA iterations, the
+// Fused element-wise passes (K4) of the FISTA / MYULA iterations (SALSA's pass is fused into the inverse
+// column FFT, fft.hip), the
 // scalar collectors and the metrics.  Every pass is 16-byte-per-lane
 // vectorised (images have an even number of elements) and every reduction is a
 // fixed-order two-level sum (per-block partials -> one block per quantity).
@@ -37,73 +38,6 @@ int ew_blocks(size_t P) {
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     return (int)nb;
-}
-
-// ---- SALSA: bu += u - x ; g = x - bu ; sums for mse / distance / criterion 2
-// (SALSA/SALSA_v2.m:440,446-451,461) ; also forms the next prox input
-// real(PTx - bu) (:429).  partials: [batch][5][nb]
-__global__ __launch_bounds__(EWB) void salsa_post_kernel(const double *__restrict__ xn,
-                                                          const double *__restrict__ xprev,
-                                                          const double *__restrict__ u, double *__restrict__ bu,
-                                                          double *__restrict__ g, const double *__restrict__ tru,
-                                                          double *__restrict__ partials, size_t P, int M, int N,
-                                                          const int *__restrict__ frozen) {
-    const int b = blockIdx.y;
-    if (frozen && frozen[b]) return;
-    __shared__ double red[6 * 4];
-    const size_t base = (size_t)b * P;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const size_t P2 = P / 2;
-    const size_t stride = (size_t)gridDim.x * EWB;
-    const size_t q0 = (size_t)blockIdx.x * EWB + threadIdx.x;
-    const size_t nloop = (P2 + stride - 1) / stride;          // uniform trip count: the shuffle below needs every lane
-    for (size_t it = 0; it < nloop; ++it) {
-        const size_t q = q0 + it * stride;
-        const bool live = q < P2;
-        const size_t o = base + 2 * (live ? q : 0);
-        const double2 xv = *reinterpret_cast<const double2 *>(xn + o);
-        const double2 uv = *reinterpret_cast<const double2 *>(u + o);
-        {
-            // periodic isotropic TV of u (utils/TVnorm.m:2) fused here: u(i-1,j) is the previous lane's
-            // second row (or a wrapped scalar load), u(i,j-1) the same rows one column to the left
-            const size_t e = 2 * (live ? q : 0);
-            const int i = (int)(e % (size_t)M), j = (int)(e / (size_t)M);
-            double up = __shfl_up(uv.y, 1, 64);
-            if ((threadIdx.x & 63) == 0 || i == 0) up = u[base + (size_t)j * M + (i > 0 ? i - 1 : M - 1)];
-            const double2 ul = *reinterpret_cast<const double2 *>(u + base + (size_t)(j > 0 ? j - 1 : N - 1) * M + i);
-            if (live) {
-                const double h0 = uv.x - ul.x, v0 = uv.x - up, h1 = uv.y - ul.y, v1 = uv.y - uv.x;
-                acc[5] += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
-            }
-        }
-        if (!live) continue;
-        double2 bv = *reinterpret_cast<const double2 *>(bu + o);
-        bv.x = bv.x + (uv.x - xv.x);
-        bv.y = bv.y + (uv.y - xv.y);
-        *reinterpret_cast<double2 *>(bu + o) = bv;
-        *reinterpret_cast<double2 *>(g + o) = make_double2(xv.x - bv.x, xv.y - bv.y);
-        if (tru) {
-            const double2 tv = *reinterpret_cast<const double2 *>(tru + o);
-            const double e0 = xv.x - tv.x, e1 = xv.y - tv.y;
-            acc[0] += e0 * e0 + e1 * e1;
-        }
-        {
-            const double d0 = xv.x - uv.x, d1 = xv.y - uv.y;
-            acc[1] += d0 * d0 + d1 * d1;
-            acc[2] += xv.x * xv.x + xv.y * xv.y;
-            acc[3] += uv.x * uv.x + uv.y * uv.y;
-        }
-        if (xprev) {
-            const double2 xo = *reinterpret_cast<const double2 *>(xprev + o);
-            const double d0 = xv.x - xo.x, d1 = xv.y - xo.y;
-            acc[4] += d0 * d0 + d1 * d1;
-        }
-    }
-    ew_block_sum<6>(acc, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) partials[((size_t)b * 6 + c) * gridDim.x + blockIdx.x] = acc[c];
-    }
 }
 
 // generic two-array sums: partials[b][4][nb] = sum (a-b)^2, sum a^2, sum b^2, max a
@@ -215,15 +149,6 @@ __global__ __launch_bounds__(EWB) void myula_step_kernel(double *__restrict__ X,
 // --------------------------------------------------------------------------
 // host wrappers
 // --------------------------------------------------------------------------
-int salsa_post(sbtv_ctx *ctx, const double *xn, const double *xprev, const double *u, double *bu, double *g,
-               const double *tru, double *partials, int M, int N, int batch, const int *frozen) {
-    const size_t P = (size_t)M * N;
-    hipLaunchKernelGGL(salsa_post_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, xn, xprev, u, bu, g,
-                       tru, partials, P, M, N, frozen);
-    SBTV_HIP(ctx, hipGetLastError());
-    return 0;
-}
-
 int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev) {
     const int nb = ew_blocks(P);
     double *partials = nullptr;

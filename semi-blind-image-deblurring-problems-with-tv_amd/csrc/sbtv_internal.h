@@ -195,10 +195,6 @@ int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int t
 // generic deterministic final reduction: out[b*nout + q] = sum_i partials[(b*nout+q)*n + i]
 int reduce_partials(sbtv_ctx *ctx, const double *partials, int nvec, int n, double *out);
 int ew_blocks(size_t P);
-// bu += u - xn ; g = xn - bu ; partials [batch][6][ew_blocks]: sum (xn-true)^2, (xn-u)^2, xn^2, u^2,
-// (xn-xprev)^2 (if xprev), periodic TV(u)
-int salsa_post(sbtv_ctx *ctx, const double *xn, const double *xprev, const double *u, double *bu, double *g,
-               const double *tru, double *partials, int M, int N, int batch, const int *frozen);
 // out4_dev[b*4 + {0,1,2,3}] = sum (a-c)^2, sum a^2, sum c^2, max a
 int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev);
 int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot);

@@ -228,7 +228,6 @@ constexpr int FCI = FRI - 2 * FH;        // core rows   (116)
 // core columns = nw*cj - 2 FHJ; minw = waves per SIMD requested from the register allocator
 struct FusedVariant { int cj; int nw; int minw; int fast; int rpl; };   // rpl = rows per lane (2: tv_fused.inc, 1: tv_fused1.inc)
 static FusedVariant g_fused = {4, 8, 4, 1, 2};
-static int g_stagger = 0;
 static inline int fused_core_cols() { return g_fused.cj * g_fused.nw - FHL - FHJ; }
 
 __device__ __forceinline__ double dpp_from_prev_lane(double v) {   // lane l gets lane l-1 (lane 0: 0)
@@ -557,10 +556,6 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
                     g_fused.rpl = rpl;
                 }
             }
-            if (const char *e = getenv("SBTV_STAGGER")) {         // tuning hook: "mode,loops"
-                int mode = 0, loops = 0;
-                if (sscanf(e, "%d,%d", &mode, &loops) == 2) g_stagger = (mode & 15) | (loops << 4);
-            }
             // SBTV_EXACT=1: IEEE div/sqrt, no FMA contraction (validation build of the arithmetic)
             if (getenv("SBTV_EXACT") != nullptr) g_fused.fast = 0;
         });
@@ -644,11 +639,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
                                g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
-                               redo, f_out, write_f, g_stagger, pl.counters, inl);                                   \
+                               redo, f_out, write_f, pl.counters, inl);                                   \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, g_stagger, pl.counters, inl);                  \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, inl);                  \
     }
             SBTV_FUSED_CASE(8, 4, 2)
             SBTV_FUSED_CASE(8, 8, 2)
