@@ -585,26 +585,49 @@ __global__ void spec_unpack_kernel(const double2 *__restrict__ S, double2 *__res
     u[(size_t)l * (n1 + 1) + k] = r;
 }
 
-// direct DFT of the zero-padded taps (utils/resize.m:1-12): U[k,l] = sum h[m,n] wM^(km) wN^(ln)
-__global__ void psf_spectrum_kernel(const double *__restrict__ taps, int taille, double2 *__restrict__ U, int n1,
-                                    int M, int N, const double2 *__restrict__ tw_M, const double2 *__restrict__ tw_N) {
+// direct DFT of the zero-padded taps (utils/resize.m:1-12): U[k,l] = sum_n c_n(k) wN^(l n) with
+// c_n(k) = sum_m h[m,n] wM^(k m).  A thread owns one k: it forms its taille column sums c_n(k) once and then
+// walks `lch` values of l with taille complex multiply-adds each (49 + 7 lch instead of 56 lch operations, in
+// the summation order of the plain double loop).  The host picks lch = 1 for small spectra, where the number
+// of threads in flight matters more than the operation count, and up to 16 for large ones.
+constexpr int PSF_TMAX = 15;    // largest PSF size (sbtv.h)
+// TT = taille known at compile time (7: every demo of the reference) -> fully unrolled, no predicates; TT = 0: any size
+template <int TT>
+__global__ __launch_bounds__(64) void psf_spectrum_kernel(const double *__restrict__ taps, int taille,
+                                                          double2 *__restrict__ U, int n1, int M, int N,
+                                                          const double2 *__restrict__ tw_M,
+                                                          const double2 *__restrict__ tw_N, int lch) {
+    constexpr int TN = TT ? TT : PSF_TMAX;
     const int b = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = blockIdx.y;
     if (k > n1) return;
     const double *h = taps + (size_t)b * taille * taille;
-    double2 acc = make_double2(0.0, 0.0);
-    for (int nn = 0; nn < taille; ++nn) {
-        double2 c = make_double2(0.0, 0.0);
-        for (int m = 0; m < taille; ++m) {
-            const double2 w = tw_M[(k * m) & (M - 1)];
-            const double hv = h[nn * taille + m];
-            c.x += hv * w.x;
-            c.y += hv * w.y;
+    double2 c[TN];
+#pragma unroll
+    for (int nn = 0; nn < TN; ++nn) {
+        double2 cc = make_double2(0.0, 0.0);
+        if (TT || nn < taille) {
+#pragma unroll
+            for (int m = 0; m < TN; ++m) {
+                if (TT || m < taille) {
+                    const double2 w = tw_M[(k * m) & (M - 1)];
+                    const double hv = h[nn * taille + m];
+                    cc.x += hv * w.x;
+                    cc.y += hv * w.y;
+                }
+            }
         }
-        acc = cadd(acc, cmul(c, tw_N[(l * nn) & (N - 1)]));
+        c[nn] = cc;
     }
-    U[(size_t)b * (n1 + 1) * N + (size_t)l * (n1 + 1) + k] = acc;
+    double2 *out = U + (size_t)b * (n1 + 1) * N + k;
+    const int l0 = blockIdx.y * lch, l1 = min(l0 + lch, N);
+    for (int l = l0; l < l1; ++l) {
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int nn = 0; nn < TN; ++nn)
+            if (TT || nn < taille) acc = cadd(acc, cmul(c[nn], tw_N[(l * nn) & (N - 1)]));
+        out[(size_t)l * (n1 + 1)] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -784,8 +807,17 @@ int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U) 
 
 int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U) {
     const int thr = 64;
-    hipLaunchKernelGGL(psf_spectrum_kernel, dim3((pl.n1 + 1 + thr - 1) / thr, pl.N, pl.batch), dim3(thr), 0,
-                       ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N);
+    if (taille > PSF_TMAX) return fail(ctx, SBTV_ERR_PSF, "PSF larger than 15 x 15");
+    const size_t elems = (size_t)(pl.n1 + 1) * pl.N * pl.batch;
+    int lch = (int)(elems >> 19);                       // 512^2, 1024^2: 1;  2048^2: 4;  8 x 1024^2: 8
+    lch = lch < 1 ? 1 : (lch > 16 ? 16 : lch);
+    const dim3 grid((pl.n1 + 1 + thr - 1) / thr, (pl.N + lch - 1) / lch, pl.batch);
+    if (taille == 7)
+        hipLaunchKernelGGL(psf_spectrum_kernel<7>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
+                           pl.tw_M, pl.tw_N, lch);
+    else
+        hipLaunchKernelGGL(psf_spectrum_kernel<0>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
+                           pl.tw_M, pl.tw_N, lch);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
