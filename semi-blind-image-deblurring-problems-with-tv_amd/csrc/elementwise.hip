@@ -129,16 +129,18 @@ __global__ __launch_bounds__(EWB) void myula_step_kernel(double *__restrict__ X,
                                                           const double *__restrict__ grad,
                                                           const double *__restrict__ Z,
                                                           const double *__restrict__ sigma2, double gam, double lamb,
-                                                          double sq2g, size_t P) {
+                                                          double sq2g, size_t P, RngArgs rng) {
     const int b = blockIdx.y;
     const size_t base = (size_t)b * P;
     const double s2 = sigma2[b];
+    const unsigned step = rng.step_dev ? (unsigned)rng.step_dev[0] : rng.step;
     for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P / 2; q += (size_t)gridDim.x * EWB) {
         const size_t o = base + 2 * q;
         const double2 xv = *reinterpret_cast<const double2 *>(X + o);
         const double2 pv = *reinterpret_cast<const double2 *>(prox + o);
         const double2 gv = *reinterpret_cast<const double2 *>(grad + o);
-        const double2 zv = *reinterpret_cast<const double2 *>(Z + o);
+        const double2 zv = Z ? *reinterpret_cast<const double2 *>(Z + o)
+                             : philox_normal_pair(q, step, rng.chain0 + (unsigned)b, rng.seed);
         double2 r;
         r.x = fabs(((xv.x + gam * (pv.x - xv.x) / lamb) - gam * (gv.x / s2)) + sq2g * zv.x);
         r.y = fabs(((xv.y + gam * (pv.y - xv.y) / lamb) - gam * (gv.y / s2)) + sq2g * zv.y);
@@ -180,9 +182,11 @@ int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, cons
 }
 
 int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
-               const double *sigma2_dev, double gam, double lamb, size_t P, int batch) {
+               const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng) {
+    if (!Z && !rng) return fail(ctx, SBTV_ERR_BADARG, "myula_step: neither a noise array nor generator arguments");
+    const RngArgs r = rng ? *rng : RngArgs{0ull, 0u, 0u, nullptr};
     hipLaunchKernelGGL(myula_step_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, X, prox, grad, Z,
-                       sigma2_dev, gam, lamb, sqrt(2 * gam), P);
+                       sigma2_dev, gam, lamb, sqrt(2 * gam), P, r);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }

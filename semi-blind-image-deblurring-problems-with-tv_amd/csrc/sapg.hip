@@ -19,45 +19,6 @@ __global__ __launch_bounds__(256) void scale_kernel(double *__restrict__ x, doub
     }
 }
 
-// ---- K9: Philox4x32-10 counter-based generator + Box-Muller -> standard normals.
-// counter = (pixel-pair index lo, hi, step, chain) ; key = seed.  One call yields 128 random bits =
-// two 53-bit uniforms = two normals = one double2 of Z.  (Statistical parity only: MATLAB's
-// randn('state',1) stream cannot be reproduced)
-__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0,
-                                             unsigned k1) {
-    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-    const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
-    c0 = h1 ^ c1 ^ k0;
-    c1 = l1;
-    c2 = h0 ^ c3 ^ k1;
-    c3 = l0;
-}
-
-__global__ __launch_bounds__(256) void randn_kernel(double *__restrict__ Z, size_t P, unsigned long long seed,
-                                                    unsigned step, unsigned chain0,
-                                                    const double *__restrict__ step_dev) {
-    const unsigned b = blockIdx.y;
-    if (step_dev) step = (unsigned)step_dev[0];      // graph replay: the step counter lives in device memory
-    const size_t P2 = P / 2;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P2; q += (size_t)gridDim.x * 256) {
-        unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = step, c3 = chain0 + b;
-        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u;
-            k1 += 0xBB67AE85u;
-        }
-        const unsigned long long a = ((unsigned long long)c0 << 32) | c1, bb = ((unsigned long long)c2 << 32) | c3;
-        const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);    // (0,1)
-        const double u2 = ((double)(bb >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-        const double r = sqrt(-2.0 * log(u1));
-        double s, c;
-        sincospi(2.0 * u2, &s, &c);
-        reinterpret_cast<double2 *>(Z + (size_t)b * P)[q] = make_double2(r * c, r * s);
-    }
-}
-
 static int launch_scale(sbtv_ctx *ctx, double *x, double a, size_t n) {
     hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, x, a, n / 2);
     SBTV_HIP(ctx, hipGetLastError());
@@ -271,9 +232,8 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt));
         }
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
-        SBTV_TRY(prox_zero_duals(ctx, pp));
         SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
-        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x));
+        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x, true));
         t = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                     // :28
         {
             std::vector<double> coef(batch, (t_old - 1) / t);            // :29
@@ -458,23 +418,29 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         return 0;
     };
     size_t noise_step = 0;
-    auto next_noise = [&]() -> int {
+    auto next_noise = [&]() -> int {          // injected noise only (the device generator runs inside the MYULA step)
         if (noise_d) {
             SBTV_HIP(ctx, hipMemcpyAsync(Z, noise_d + noise_step * cnt, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
         } else if (noise_host) {
             SBTV_HIP(ctx, hipMemcpyAsync(Z, noise + noise_step * cnt, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed,
-                               (unsigned)noise_step, (unsigned)op->chain_offset, (const double *)nullptr);
-            SBTV_HIP(ctx, hipGetLastError());
         }
         ++noise_step;
         return 0;
     };
+    // X <- |X + gam (prox - X)/lamb - gam gradF + sqrt(2 gam) Z|  (:80-81,160-161).  With the device generator the
+    // normals are drawn inside the step kernel (no Z array is written or read); injected noise goes through Z.
+    auto myula = [&](bool in_graph) -> int {
+        if (noise) {
+            SBTV_TRY(next_noise());
+            return myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch);
+        }
+        const RngArgs r{op->seed, (unsigned)noise_step, (unsigned)op->chain_offset, in_graph ? step_d : nullptr};
+        if (!in_graph) ++noise_step;
+        return myula_step(ctx, X, prox, grad, nullptr, sig_d, gam, lamb, P, batch, &r);
+    };
     auto do_prox = [&]() -> int {   // prox = chambolle(X, lambda*theta, cold start)
-        SBTV_TRY(prox_zero_duals(ctx, pp));
         SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
-        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox));
+        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox, true));
         return 0;
     };
 
@@ -510,9 +476,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
             SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         }
-        hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks(P), batch), dim3(256), 0, ctx->stream, Z, P, op->seed, 0u,
-                           (unsigned)op->chain_offset, (const double *)step_d);
-        SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));
+        SBTV_TRY(myula(true));
         SBTV_TRY(do_prox());
         SBTV_TRY(operator_pass(main_loop ? !params_move : true));
         SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
@@ -586,8 +550,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             bool replayed = false;
             if (use_graph && ii >= 3) SBTV_TRY(graph_iteration(&g_warm, false, theta, &replayed));
             if (!replayed) {
-                SBTV_TRY(next_noise());
-                SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));        // :80-81
+                SBTV_TRY(myula(false));                                                           // :80-81
                 SBTV_TRY(do_prox());                                                               // :82
                 SBTV_TRY(operator_pass(true));
                 SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
@@ -639,8 +602,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         }
         if (!replayed) {
             SBTV_TRY(upload_lam_sigma(theta));                                                    // theta(ii-1), sigma(ii-1)
-            SBTV_TRY(next_noise());
-            SBTV_TRY(myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch));             // :160-161
+            SBTV_TRY(myula(false));                                                                // :160-161
             SBTV_TRY(do_prox());                                                                   // :162
             SBTV_TRY(operator_pass(!params_move));                                                 // G_w*, G_s, f  (:170-188)
             SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));                // g(X)          (:165)

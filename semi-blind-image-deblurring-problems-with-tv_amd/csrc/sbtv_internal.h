@@ -102,6 +102,44 @@ int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int
 int stage_out_buf(sbtv_ctx *ctx, const char *name, double *p, size_t count, int flags, double **dev);
 int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count, int flags);
 
+// ---- K9: Philox4x32-10 counter-based generator + Box-Muller -> standard normals.
+// counter = (pixel-pair index lo, hi, step, chain) ; key = seed.  One call yields 128 random bits =
+// two 53-bit uniforms = two normals = one double2 of Z.  (Statistical parity only: MATLAB's
+// randn('state',1) stream cannot be reproduced)
+__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0,
+                                             unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+    c0 = h1 ^ c1 ^ k0;
+    c1 = l1;
+    c2 = h0 ^ c3 ^ k1;
+    c3 = l0;
+}
+__device__ __forceinline__ double2 philox_normal_pair(size_t q, unsigned step, unsigned chain, unsigned long long seed) {
+#pragma clang fp contract(off)      // the same bits from every translation unit that draws these numbers
+    unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = step, c3 = chain;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const unsigned long long a = ((unsigned long long)c0 << 32) | c1, bb = ((unsigned long long)c2 << 32) | c3;
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);    // (0,1)
+    const double u2 = ((double)(bb >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    return make_double2(r * c, r * s);
+}
+// where the in-kernel generator of the MYULA step takes its counters from
+struct RngArgs {
+    unsigned long long seed;
+    unsigned step, chain0;
+    const double *step_dev;     // non-null: the step counter lives in device memory (graph replay)
+};
+
 // hipGraph replay of launch-bound iteration bodies (ctx.hip)
 bool graph_wanted(size_t total_px);
 int graph_begin(sbtv_ctx *ctx);
@@ -128,7 +166,10 @@ int prox_set_duals(sbtv_ctx *ctx, const ProxPlan &pl, const double *px, const do
 int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);               // device ptrs
 // Run up to `maxiter` iterations (device-side early exit), no host sync.
 // If f_out is given it receives f = g - lambda div p (fused into the last launch where possible).
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr);
+// cold = true: start from px = py = 0 without reading (or requiring the caller to clear) the dual buffer; the
+// control block must have been reset with keep_cur = false.
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr,
+                 bool cold = false);
 // f = g - lambda * div(p)
 int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
 // periodic TV norm of x -> out_dev[batch] (device)
@@ -200,8 +241,9 @@ int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int bat
 int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot);
 int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, const double *coef_dev,
                    double *partials, size_t P, int batch, const int *frozen);
+// Z == nullptr: the normals are drawn in the kernel from `rng` (the numbers randn_kernel would have stored)
 int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
-               const double *sigma2_dev, double gam, double lamb, size_t P, int batch);
+               const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng = nullptr);
 int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S, const int *frozen);
 int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen);
 

@@ -614,7 +614,7 @@ int g_force_single_step = 0;   // test hook (SBTV_SINGLE_STEP=1): one-iteration 
 
 int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
 
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out) {
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold) {
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
     const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
     static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
@@ -633,17 +633,18 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         auto launch_fused = [&](int steps, int redo, int write_f) {
             bool launched = false;
             const int inl = (!redo && env_inline) ? 1 : 0;
+            const int kflags = inl | (cold ? 2 : 0);            // bit 0: in-kernel stop rule, bit 1: cold start
 #define SBTV_FUSED_CASE(CJ_, NW_, MW_)                                                                               \
     if (g_fused.rpl == 2 && g_fused.cj == CJ_ && g_fused.nw == NW_ && g_fused.minw == MW_) {                         \
         launched = true;                                                                                             \
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
                                g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
-                               redo, f_out, write_f, pl.counters, inl);                                   \
+                               redo, f_out, write_f, pl.counters, kflags);                                   \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, inl);                  \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags);                  \
     }
             SBTV_FUSED_CASE(8, 4, 2)
             SBTV_FUSED_CASE(8, 8, 2)
@@ -665,11 +666,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused1_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, inl);                             \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags);                             \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused1_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,            \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, inl);                             \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags);                             \
     }
             SBTV_FUSED1_CASE(4, 8, 6)
             SBTV_FUSED1_CASE(4, 8, 5)
@@ -692,6 +693,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
+    if (cold) SBTV_TRY(prox_zero_duals(ctx, pl));     // the one-iteration kernels read the duals from memory
     for (int it = 0; it < maxiter; ++it) {
         if (v)
             hipLaunchKernelGGL(chambolle_iter_kernel<true>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl,
@@ -781,12 +783,10 @@ int sbtv_chambolle_prox_TV_stop(sbtv_ctx *ctx, const double *g, int M, int N, in
         SBTV_TRY(stage_in(ctx, "prox.in.px", px, cnt, flags, &pxd));
         SBTV_TRY(stage_in(ctx, "prox.in.py", py, cnt, flags, &pyd));
         SBTV_TRY(prox_set_duals(ctx, pl, pxd, pyd));
-    } else {
-        SBTV_TRY(prox_zero_duals(ctx, pl));
     }
     double *fd = nullptr, *pxo = nullptr, *pyo = nullptr;
     if (f) SBTV_TRY(stage_out_buf(ctx, "prox.out.f", f, cnt, flags, &fd));
-    SBTV_TRY(prox_iterate(ctx, pl, gd, maxiter, fd));
+    SBTV_TRY(prox_iterate(ctx, pl, gd, maxiter, fd, !warm_start));     // cold start: px = py = 0 (:68-69)
     if (f) SBTV_TRY(stage_out_copy(ctx, f, fd, cnt, flags));
     if (px && py) {
         SBTV_TRY(stage_out_buf(ctx, "prox.out.px", px, cnt, flags, &pxo));
