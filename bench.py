@@ -194,6 +194,8 @@ def main():
             "roofline": {"kernel": "chambolle_fused_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+                         # physical side of the same launch: PMC bytes / measured time, as a fraction of the HBM peak
+                         "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "iterations_per_launch": FUSED_STEPS,
                          "us_per_chambolle_iteration": 1e3 * tm["chambolle_ms"] / max(iters, 1),
                          "note": "5 iterations fused per launch (temporal blocking): the algorithmic bytes "
