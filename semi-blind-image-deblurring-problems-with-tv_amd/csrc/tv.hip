@@ -228,7 +228,7 @@ constexpr int FCI = FRI - 2 * FH;        // core rows   (116)
 // core columns = nw*cj - 2 FHJ; minw = waves per SIMD requested from the register allocator
 struct FusedVariant { int cj; int nw; int minw; int fast; int rpl; };   // rpl = rows per lane (2: tv_fused.inc, 1: tv_fused1.inc)
 static FusedVariant g_fused = {4, 8, 4, 1, 2};
-static inline int fused_core_cols() { return g_fused.cj * g_fused.nw - FHL - FHJ; }
+static bool g_fused_forced = false;             // SBTV_FUSED_VARIANT given: no per-plan choice
 
 __device__ __forceinline__ double dpp_from_prev_lane(double v) {   // lane l gets lane l-1 (lane 0: 0)
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -550,6 +550,7 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
                 if (sscanf(e, "%d,%d,%d,%d", &cj, &nw, &mw, &rpl) >= 3)
                     for (auto &k4 : known) ok = ok || (k4[0] == cj && k4[1] == nw && k4[2] == mw && k4[3] == rpl);
                 if (ok) {
+                    g_fused_forced = true;
                     g_fused.cj = cj;
                     g_fused.nw = nw;
                     g_fused.minw = mw;
@@ -560,12 +561,24 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
             if (getenv("SBTV_EXACT") != nullptr) g_fused.fast = 0;
         });
     }
-    {
-        const int core_rows = (g_fused.rpl == 1) ? F1CI : FCI;
+    // tile geometry of this plan: the process-wide variant, except that a grid which would not even give every CU
+    // one 128-row tile (e.g. 512^2: 125 tiles) takes the 64-row one-row-per-lane tiles instead (twice the
+    // workgroups; measured -7 % per SAPG iteration at 512^2), unless a variant was forced
+    auto geometry = [&](int cj, int nw, int rpl) {
+        const int core_rows = (rpl == 1) ? F1CI : FCI, core_cols = cj * nw - FHL - FHJ;
         pl->ftiles_i = (M + core_rows - 1) / core_rows;
+        pl->ftiles_j = (N + core_cols - 1) / core_cols;
+        pl->fnblk = pl->ftiles_i * pl->ftiles_j;
+        pl->cj = cj;
+        pl->nw = nw;
+        pl->rpl = rpl;
+    };
+    geometry(g_fused.cj, g_fused.nw, g_fused.rpl);
+    pl->minw = g_fused.minw;
+    if (!g_fused_forced && (size_t)pl->fnblk * batch < 256) {
+        geometry(4, 8, 1);
+        pl->minw = 4;
     }
-    pl->ftiles_j = (N + fused_core_cols() - 1) / fused_core_cols();
-    pl->fnblk = pl->ftiles_i * pl->ftiles_j;
     const size_t P = (size_t)M * N;
     size_t npart = (size_t)batch * pl->nblk;
     if ((size_t)batch * FH * pl->fnblk > npart) npart = (size_t)batch * FH * pl->fnblk;
@@ -635,7 +648,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             const int inl = (!redo && env_inline) ? 1 : 0;
             const int kflags = inl | (cold ? 2 : 0);            // bit 0: in-kernel stop rule, bit 1: cold start
 #define SBTV_FUSED_CASE(CJ_, NW_, MW_)                                                                               \
-    if (g_fused.rpl == 2 && g_fused.cj == CJ_ && g_fused.nw == NW_ && g_fused.minw == MW_) {                         \
+    if (pl.rpl == 2 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {                         \
         launched = true;                                                                                             \
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
@@ -661,7 +674,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED_CASE(5, 8, 4)
 #undef SBTV_FUSED_CASE
 #define SBTV_FUSED1_CASE(CJ_, NW_, MW_)                                                                              \
-    if (g_fused.rpl == 1 && g_fused.cj == CJ_ && g_fused.nw == NW_ && g_fused.minw == MW_) {                         \
+    if (pl.rpl == 1 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {                         \
         launched = true;                                                                                             \
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused1_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0,             \

@@ -47,7 +47,8 @@ def test_exact_fast_single_step_and_tile_variants_agree(tmp_path):
         "tile_8_4": {"SBTV_FUSED_VARIANT": "8,4,2"},        # other tile geometry of the fused kernel
         "tile_16_4": {"SBTV_FUSED_VARIANT": "16,4,1"},
         "nospec": {"SBTV_FUSED_VARIANT": "4,8,2"},
-        "rows1": {"SBTV_FUSED_VARIANT": "4,8,4,1"},         # one row per lane (64-row tiles)
+        "rows1": {"SBTV_FUSED_VARIANT": "4,8,4,1"},         # one row per lane (64-row tiles; the default on small grids)
+        "rows2": {"SBTV_FUSED_VARIANT": "4,8,4"},           # the 128-row tiles large images get, forced on these small ones
         "inline": {"SBTV_INLINE_CTRL": "1"},                # stop rule applied by the last workgroup of a launch
         "separate": {"SBTV_INLINE_CTRL": "0"},              # ... or always by the separate control kernel
     }
