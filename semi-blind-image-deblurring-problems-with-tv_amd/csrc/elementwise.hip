@@ -129,8 +129,22 @@ __global__ __launch_bounds__(EWB) void myula_step_kernel(double *__restrict__ X,
                                                           const double *__restrict__ grad,
                                                           const double *__restrict__ Z,
                                                           const double *__restrict__ sigma2, double gam, double lamb,
-                                                          double sq2g, size_t P, RngArgs rng) {
+                                                          double sq2g, size_t P, RngArgs rng, ProxArm arm) {
     const int b = blockIdx.y;
+    if (arm.ctrl && blockIdx.x == 0 && threadIdx.x == 0) {
+        ProxCtrl c = arm.ctrl[b];          // prox_reset(keep_cur = false) for the cold-start prox that follows
+        c.k = 0;
+        c.done = 0;
+        c.cur = 0;
+        c.maxiter = arm.maxiter;
+        c.redo = 0;
+        c.f_valid = 0;
+        c.err = 0.0;
+        c.lambda = arm.lambda[b];
+        c.tol = arm.tol;
+        c.tau = arm.tau;
+        arm.ctrl[b] = c;
+    }
     const size_t base = (size_t)b * P;
     const double s2 = sigma2[b];
     const unsigned step = rng.step_dev ? (unsigned)rng.step_dev[0] : rng.step;
@@ -182,11 +196,13 @@ int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, cons
 }
 
 int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
-               const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng) {
+               const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng,
+               const ProxArm *arm) {
     if (!Z && !rng) return fail(ctx, SBTV_ERR_BADARG, "myula_step: neither a noise array nor generator arguments");
     const RngArgs r = rng ? *rng : RngArgs{0ull, 0u, 0u, nullptr};
+    const ProxArm pa = arm ? *arm : ProxArm{nullptr, nullptr, 0, 0.0, 0.0};
     hipLaunchKernelGGL(myula_step_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, X, prox, grad, Z,
-                       sigma2_dev, gam, lamb, sqrt(2 * gam), P, r);
+                       sigma2_dev, gam, lamb, sqrt(2 * gam), P, r, pa);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }

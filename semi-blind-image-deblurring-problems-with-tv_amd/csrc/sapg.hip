@@ -25,6 +25,25 @@ static int launch_scale(sbtv_ctx *ctx, double *x, double a, size_t n) {
     return 0;
 }
 
+// SAPG scalars of one iteration in one launch: block (q, b) reduces, in a fixed order, the rows-kernel accumulator
+// q < 3 of image b (||AX-y||^2 and the two <dA_p X, AX-y> sums, [batch][3][nrb]) or, for q = 3, the periodic-TV
+// partials ([batch][ntv]) and writes the total where the host reads it: out[b*3 + q] resp. out[3*batch + b].
+// `out` is the device view of pinned host memory, so no copy kernel follows.
+__global__ __launch_bounds__(256) void sapg_collect_kernel(const double *__restrict__ acc, int nrb,
+                                                           const double *__restrict__ tvp, int ntv,
+                                                           double *__restrict__ out, int batch) {
+    __shared__ double red[4];
+    const int q = blockIdx.x, b = blockIdx.y;
+    const double *p = (q < 3) ? acc + ((size_t)b * 3 + q) * nrb : tvp + (size_t)b * ntv;
+    const int n = (q < 3) ? nrb : ntv;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(q < 3) ? (size_t)b * 3 + q : 3 * (size_t)batch + b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // sums of the rows-kernel accumulators: out[b*3 + c]
 static int reduce_acc(sbtv_ctx *ctx, const double *acc, int batch, int nrb, double *out_dev) {
     return reduce_partials(ctx, acc, batch * 3, nrb, out_dev);
@@ -340,14 +359,19 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     double *taps_d = par, *d0_d = par + t2 * nspec, *d1_d = par + 2 * t2 * nspec, *lam_d = par + 3 * t2 * nspec,
            *sig_d = lam_d + batch, *step_d = sig_d + batch;
     const int nrb = fft_rows_blocks(fp);
-    double *acc = nullptr, *scal_d = nullptr;
+    double *acc = nullptr;
     SBTV_TRY(ws_get_t(ctx, "sapg.acc", (size_t)batch * 3 * nrb, &acc));
-    SBTV_TRY(ws_get_t(ctx, "sapg.scal", (size_t)batch * 4, &scal_d));     // [acc3 per image | tv per image]
     double *scal_h = nullptr;
     {
         void *pz = nullptr;
         SBTV_TRY(pinned_get(ctx, sizeof(double) * (4 * batch + 3 * t2 * nspec + 2 * batch + 1), &pz));
         scal_h = static_cast<double *>(pz);
+    }
+    double *scal_hd = nullptr;                        // the same pinned scalars as the device sees them
+    {
+        void *dp = nullptr;
+        SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, scal_h, 0));
+        scal_hd = static_cast<double *>(dp);
     }
     double *par_h = scal_h + 4 * (size_t)batch;       // pinned staging for the per-iteration parameter upload
     const double inv_scale = 1.0 / ((double)fp.n1 * N), parseval = 1.0 / ((double)M * N);
@@ -409,11 +433,21 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
         SBTV_TRY(fft_rows(ctx, fp, S, want_grad ? S : nullptr, a));
         if (want_grad) SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
-        SBTV_TRY(reduce_acc(ctx, acc, batch, nrb, scal_d));
+        return 0;
+    };
+    // TVnorm(X) partials + ONE collector launch that reduces them together with the accumulators of the last
+    // operator pass straight into pinned host memory (no separate reductions, no copy kernel)
+    auto collect_scalars = [&]() -> int {
+        double *tvp = nullptr;
+        int ntv = 0;
+        SBTV_TRY(tvnorm_partials(ctx, X, M, N, batch, &tvp, &ntv));
+        hipLaunchKernelGGL(sapg_collect_kernel, dim3(4, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
+                           (const double *)tvp, ntv, scal_hd, batch);
+        SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
     auto fetch_scalars = [&]() -> int {
-        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(double) * 4 * batch, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_TRY(collect_scalars());
         SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return 0;
     };
@@ -429,17 +463,20 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     };
     // X <- |X + gam (prox - X)/lamb - gam gradF + sqrt(2 gam) Z|  (:80-81,160-161).  With the device generator the
     // normals are drawn inside the step kernel (no Z array is written or read); injected noise goes through Z.
+    // The step kernel also re-arms the prox control blocks for the cold-start prox that always follows it.
+    const ProxArm arm{pp.ctrl, lam_d, op->chambolleit, 1e-3, 0.249};
     auto myula = [&](bool in_graph) -> int {
         if (noise) {
             SBTV_TRY(next_noise());
-            return myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch);
+            return myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch, nullptr, &arm);
         }
         const RngArgs r{op->seed, (unsigned)noise_step, (unsigned)op->chain_offset, in_graph ? step_d : nullptr};
         if (!in_graph) ++noise_step;
-        return myula_step(ctx, X, prox, grad, nullptr, sig_d, gam, lamb, P, batch, &r);
+        return myula_step(ctx, X, prox, grad, nullptr, sig_d, gam, lamb, P, batch, &r, &arm);
     };
-    auto do_prox = [&]() -> int {   // prox = chambolle(X, lambda*theta, cold start)
-        SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
+    // prox = chambolle(X, lambda*theta, cold start); armed: the MYULA step before it has reset the control blocks
+    auto do_prox = [&](bool armed) -> int {
+        if (!armed) SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
         SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox, true));
         return 0;
     };
@@ -477,10 +514,9 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         }
         SBTV_TRY(myula(true));
-        SBTV_TRY(do_prox());
+        SBTV_TRY(do_prox(true));
         SBTV_TRY(operator_pass(main_loop ? !params_move : true));
-        SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
-        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(double) * 4 * batch, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_TRY(collect_scalars());
         return 0;
     };
     // host side of one replayed iteration: stage the parameters, launch, wait for the scalars
@@ -544,16 +580,15 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     SBTV_TRY(refresh_spectra());
     if (warmup > 0) {
         SBTV_TRY(upload_lam_sigma(theta));
-        SBTV_TRY(do_prox());
+        SBTV_TRY(do_prox(false));
         SBTV_TRY(operator_pass(true));                       // grad for the first step
         for (int ii = 2; ii <= warmup; ++ii) {
             bool replayed = false;
             if (use_graph && ii >= 3) SBTV_TRY(graph_iteration(&g_warm, false, theta, &replayed));
             if (!replayed) {
                 SBTV_TRY(myula(false));                                                           // :80-81
-                SBTV_TRY(do_prox());                                                               // :82
+                SBTV_TRY(do_prox(true));                                                               // :82
                 SBTV_TRY(operator_pass(true));
-                SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
                 SBTV_TRY(fetch_scalars());
             }
             if (logpi_wu)
@@ -566,7 +601,6 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
 
     // =========================== SAPG loop (:98-248) ===========================
     // slot 0 of the traces (ii = 1)
-    SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));
     SBTV_TRY(fetch_scalars());
     for (int b = 0; b < batch; ++b) {
         if (thetas) thetas[(size_t)b * samples] = theta[b];
@@ -579,7 +613,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         if (op->burnIn == 1) { sum_th[b] += theta[b]; sum_s[b] += sig2[b]; sum_p0[b] += p0[b]; sum_p1[b] += p1[b]; }
     }
     SBTV_TRY(upload_lam_sigma(theta));
-    SBTV_TRY(do_prox());                                      // proxGX = proxG(X, thetas(1))   (:134)
+    SBTV_TRY(do_prox(false));                                      // proxGX = proxG(X, thetas(1))   (:134)
     for (int ii = 2; ii <= samples; ++ii) {
         const int i0 = ii - 1;
         bool replayed = false;
@@ -603,10 +637,9 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         if (!replayed) {
             SBTV_TRY(upload_lam_sigma(theta));                                                    // theta(ii-1), sigma(ii-1)
             SBTV_TRY(myula(false));                                                                // :160-161
-            SBTV_TRY(do_prox());                                                                   // :162
+            SBTV_TRY(do_prox(true));                                                                   // :162
             SBTV_TRY(operator_pass(!params_move));                                                 // G_w*, G_s, f  (:170-188)
-            SBTV_TRY(tvnorm_dev(ctx, X, M, N, batch, scal_d + 3 * (size_t)batch));                // g(X)          (:165)
-            SBTV_TRY(fetch_scalars());
+            SBTV_TRY(fetch_scalars());                                                             // incl. g(X)  (:165)
         }
         const double delta = op->d_scale * (pow((double)ii, -op->d_exp) / dimX);              // :55
         // per-chain gradients

@@ -140,6 +140,15 @@ struct RngArgs {
     const double *step_dev;     // non-null: the step counter lives in device memory (graph replay)
 };
 
+// lets the MYULA step kernel (which runs right before the cold-start prox) re-arm the prox control blocks, i.e. do
+// what prox_reset does with keep_cur = false and no frozen images, and so save that launch
+struct ProxArm {
+    ProxCtrl *ctrl;             // [batch]; nullptr: nothing to arm
+    const double *lambda;       // [batch] (device)
+    int maxiter;
+    double tol, tau;
+};
+
 // hipGraph replay of launch-bound iteration bodies (ctx.hip)
 bool graph_wanted(size_t total_px);
 int graph_begin(sbtv_ctx *ctx);
@@ -244,7 +253,8 @@ int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, cons
                    double *partials, size_t P, int batch, const int *frozen);
 // Z == nullptr: the normals are drawn in the kernel from `rng` (the numbers randn_kernel would have stored)
 int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
-               const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng = nullptr);
+               const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng = nullptr,
+               const ProxArm *arm = nullptr);
 int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S, const int *frozen);
 int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen);
 
