@@ -229,15 +229,16 @@ int sbtv_ctx_create(int device, sbtv_ctx **out) {
 
 int sbtv_ctx_destroy(sbtv_ctx *ctx) {
     if (!ctx) return 0;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    // teardown: release everything even if one call fails (nothing useful can be done about it here)
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->ws)
-        if (kv.second.p) hipFree(kv.second.p);
-    for (auto &kv : ctx->twiddles) hipFree(kv.second);
-    if (ctx->pinned) hipHostFree(ctx->pinned);
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : ctx->twiddles) (void)hipFree(kv.second);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &ev : ctx->ev)
-        if (ev) hipEventDestroy(ev);
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
 }
