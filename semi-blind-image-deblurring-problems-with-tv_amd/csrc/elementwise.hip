@@ -82,7 +82,22 @@ __global__ __launch_bounds__(256) void reduce_max_kernel(const double *__restric
 // ---- FISTA (SALSA/my_fista.m:25,29)
 //   grad step : y = y - (1/L) * grad
 __global__ __launch_bounds__(EWB) void axpy_kernel(double *__restrict__ y, const double *__restrict__ gr, double a,
-                                                    size_t Ptot) {
+                                                    size_t Ptot, ProxArm arm, int batch) {
+    if (arm.ctrl && blockIdx.x == 0 && (int)threadIdx.x < batch) {
+        const int b = threadIdx.x;         // prox_reset(keep_cur = false) for the cold-start prox that follows
+        ProxCtrl c = arm.ctrl[b];
+        c.k = 0;
+        c.done = (arm.frozen && arm.frozen[b]) ? 1 : 0;
+        c.cur = 0;
+        c.maxiter = arm.maxiter;
+        c.redo = 0;
+        c.f_valid = 0;
+        c.err = 0.0;
+        c.lambda = arm.lambda[b];
+        c.tol = arm.tol;
+        c.tau = arm.tau;
+        arm.ctrl[b] = c;
+    }
     for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < Ptot / 2; q += (size_t)gridDim.x * EWB) {
         double2 yv = *reinterpret_cast<double2 *>(y + 2 * q);
         const double2 gv = *reinterpret_cast<const double2 *>(gr + 2 * q);
@@ -94,14 +109,12 @@ __global__ __launch_bounds__(EWB) void axpy_kernel(double *__restrict__ y, const
 //   momentum  : y = x + c (x - x_old) ; x_old = x ; sums (x-true)^2, (x-x_old)^2, x^2   partials [batch][3][nb]
 __global__ __launch_bounds__(EWB) void fista_momentum_kernel(const double *__restrict__ x, double *__restrict__ xold,
                                                               double *__restrict__ y, const double *__restrict__ tru,
-                                                              const double *__restrict__ coef,
-                                                              double *__restrict__ partials, size_t P,
+                                                              double c, double *__restrict__ partials, size_t P,
                                                               const int *__restrict__ frozen) {
     const int b = blockIdx.y;
     if (frozen && frozen[b]) return;
     __shared__ double red[3 * 4];
     const size_t base = (size_t)b * P;
-    const double c = coef[b];
     double acc[3] = {0, 0, 0};
     for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P / 2; q += (size_t)gridDim.x * EWB) {
         const size_t o = base + 2 * q;
@@ -181,16 +194,18 @@ int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int bat
     return 0;
 }
 
-int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot) {
-    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(Ptot)), dim3(EWB), 0, ctx->stream, y, gr, a, Ptot);
+int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot, const ProxArm *arm, int batch) {
+    if (arm && batch > EWB) return fail(ctx, SBTV_ERR_BADARG, "axpy: cannot arm more than 256 control blocks");
+    const ProxArm pa = arm ? *arm : ProxArm{nullptr, nullptr, 0, 0.0, 0.0, nullptr};
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(Ptot)), dim3(EWB), 0, ctx->stream, y, gr, a, Ptot, pa, batch);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
 
-int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, const double *coef_dev,
+int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, double coef,
                    double *partials, size_t P, int batch, const int *frozen) {
     hipLaunchKernelGGL(fista_momentum_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, x, xold, y, tru,
-                       coef_dev, partials, P, frozen);
+                       coef, partials, P, frozen);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -200,7 +215,7 @@ int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad,
                const ProxArm *arm) {
     if (!Z && !rng) return fail(ctx, SBTV_ERR_BADARG, "myula_step: neither a noise array nor generator arguments");
     const RngArgs r = rng ? *rng : RngArgs{0ull, 0u, 0u, nullptr};
-    const ProxArm pa = arm ? *arm : ProxArm{nullptr, nullptr, 0, 0.0, 0.0};
+    const ProxArm pa = arm ? *arm : ProxArm{nullptr, nullptr, 0, 0.0, 0.0, nullptr};
     hipLaunchKernelGGL(myula_step_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, X, prox, grad, Z,
                        sigma2_dev, gam, lamb, sqrt(2 * gam), P, r, pa);
     SBTV_HIP(ctx, hipGetLastError());

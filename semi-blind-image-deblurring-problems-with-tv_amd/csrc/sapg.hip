@@ -44,6 +44,40 @@ __global__ __launch_bounds__(256) void sapg_collect_kernel(const double *__restr
     if (threadIdx.x == 0) out[(q < 3) ? (size_t)b * 3 + q : 3 * (size_t)batch + b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// FISTA scalars of one iteration in one launch: block (q, b): q < 3 rows-kernel accumulators [batch][3][nrb] ->
+// out[b*3+q]; q = 3..5 momentum-kernel sums [batch][3][npb] (may be null) -> out[3*batch + b*3 + (q-3)];
+// q = 6 periodic-TV partials [batch][ntv] -> out[6*batch + b].  `out` is the device view of pinned host memory.
+__global__ __launch_bounds__(256) void fista_collect_kernel(const double *__restrict__ acc, int nrb,
+                                                            const double *__restrict__ mom, int npb,
+                                                            const double *__restrict__ tvp, int ntv,
+                                                            double *__restrict__ out, int batch) {
+    __shared__ double red[4];
+    const int q = blockIdx.x, b = blockIdx.y;
+    const double *p;
+    int n;
+    size_t o;
+    if (q < 3) {
+        p = acc + ((size_t)b * 3 + q) * nrb;
+        n = nrb;
+        o = (size_t)b * 3 + q;
+    } else if (q < 6) {
+        p = mom ? mom + ((size_t)b * 3 + (q - 3)) * npb : nullptr;
+        n = npb;
+        o = 3 * (size_t)batch + (size_t)b * 3 + (q - 3);
+    } else {
+        p = tvp + (size_t)b * ntv;
+        n = ntv;
+        o = 6 * (size_t)batch + b;
+    }
+    double s = 0.0;
+    if (p)
+        for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[o] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // sums of the rows-kernel accumulators: out[b*3 + c]
 static int reduce_acc(sbtv_ctx *ctx, const double *acc, int batch, int nrb, double *out_dev) {
     return reduce_partials(ctx, acc, batch * 3, nrb, out_dev);
@@ -148,7 +182,7 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     const size_t npar = (size_t)batch * taille * taille + 2 * (size_t)batch;
     double *par = nullptr;
     SBTV_TRY(ws_get_t(ctx, "fista.par", npar, &par));
-    double *taps_d = par, *lam_d = par + (size_t)batch * taille * taille, *coef_d = lam_d + batch;
+    double *taps_d = par, *lam_d = par + (size_t)batch * taille * taille;
     std::vector<double> hpar(npar);
     for (size_t q = 0; q < (size_t)batch * taille * taille; ++q) hpar[q] = taps[q];
     for (int b = 0; b < batch; ++b) {
@@ -160,16 +194,17 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_TRY(ws_get_t(ctx, "fista.frozen", (size_t)batch, &frozen_d));
     SBTV_HIP(ctx, hipMemsetAsync(frozen_d, 0, sizeof(int) * batch, ctx->stream));
     const int nrb = fft_rows_blocks(fp), npb = ew_blocks(P);
-    double *acc = nullptr, *momp = nullptr, *scal_d = nullptr, *o4 = nullptr;
+    double *acc = nullptr, *momp = nullptr, *o4 = nullptr;
     SBTV_TRY(ws_get_t(ctx, "fista.acc", (size_t)batch * 3 * nrb, &acc));
     SBTV_TRY(ws_get_t(ctx, "fista.momp", (size_t)batch * 3 * npb, &momp));
-    SBTV_TRY(ws_get_t(ctx, "fista.scal", (size_t)batch * 8, &scal_d));   // [acc3 | mom3 | tv | pad]
     SBTV_TRY(ws_get_t(ctx, "fista.o4", (size_t)batch * 4, &o4));
-    double *scal_h = nullptr;
+    double *scal_h = nullptr, *scal_hd = nullptr;      // pinned [acc3 | mom3 | tv | pad] per image, host / device view
     {
-        void *pz = nullptr;
+        void *pz = nullptr, *dp = nullptr;
         SBTV_TRY(pinned_get(ctx, sizeof(double) * 8 * batch, &pz));
         scal_h = static_cast<double *>(pz);
+        SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
+        scal_hd = static_cast<double *>(dp);
     }
     const double inv_scale = 1.0 / ((double)fp.n1 * N), parseval = 1.0 / ((double)M * N);
     SBTV_TRY(psf_spectrum(ctx, fp, taps_d, taille, Hs));
@@ -197,7 +232,9 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_HIP(ctx, hipMemcpyAsync(xold, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
 
     // objective(k) = 0.5*||A x - b||^2 + tau*Phi(x) ; mses(k)   (:14-15, :31-33)
-    auto objective_of_x = [&](const int *frozen) -> int {
+    // residual energy (Parseval) and TV partials of x, then ONE collector launch that reduces them (and the
+    // momentum-kernel sums when given) straight into pinned host memory
+    auto objective_of_x = [&](const int *frozen, const double *mom_partials) -> int {
         RowsArgs a{};
         a.dir_fwd = 1;
         a.op = OP_RESID;
@@ -207,18 +244,21 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         a.frozen = frozen;
         SBTV_TRY(fft_cols_fwd_f(ctx, fp, x, nullptr, S, frozen));
         SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
-        SBTV_TRY(reduce_acc(ctx, acc, batch, nrb, scal_d));                       // scal[b*3 + c] (first 3*batch)
-        SBTV_TRY(tvnorm_dev(ctx, x, M, N, batch, scal_d + 6 * (size_t)batch));    // tv at [6*batch + b]
+        double *tvp = nullptr;
+        int ntv = 0;
+        SBTV_TRY(tvnorm_partials(ctx, x, M, N, batch, &tvp, &ntv));
+        hipLaunchKernelGGL(fista_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
+                           mom_partials, npb, (const double *)tvp, ntv, scal_hd, batch);
+        SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
     auto fetch = [&]() -> int {
-        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(double) * 8 * batch, hipMemcpyDeviceToHost, ctx->stream));
         SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return 0;
     };
     std::vector<double> obj_prev(batch, 0.0);
     std::vector<int> frozen(batch, 0), h_niter(batch, 1);
-    SBTV_TRY(objective_of_x(nullptr));
+    SBTV_TRY(objective_of_x(nullptr, nullptr));
     SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
     {
         std::vector<double> h4((size_t)batch * 4);
@@ -248,20 +288,20 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             SBTV_TRY(fft_cols_fwd_f(ctx, fp, y, nullptr, S, frozen_d));
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
             SBTV_TRY(fft_cols_inv_f(ctx, fp, S, grad, inv_scale, frozen_d));
-            SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt));
+            // the gradient-step kernel also re-arms the control blocks of the cold-start prox that follows
+            const ProxArm arm{pp.ctrl, lam_d, prox_iters, 1e-3, 0.249, frozen_d};
+            if (batch <= 256) {
+                SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt, &arm, batch));
+            } else {
+                SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt));
+                SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
+            }
         }
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
-        SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
         SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x, true));
         t = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                     // :28
-        {
-            std::vector<double> coef(batch, (t_old - 1) / t);            // :29
-            SBTV_HIP(ctx, hipMemcpyAsync(coef_d, coef.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
-            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        SBTV_TRY(fista_momentum(ctx, x, xold, y, td, coef_d, momp, P, batch, frozen_d));
-        SBTV_TRY(reduce_partials(ctx, momp, batch * 3, npb, scal_d + 3 * (size_t)batch));
-        SBTV_TRY(objective_of_x(frozen_d));
+        SBTV_TRY(fista_momentum(ctx, x, xold, y, td, (t_old - 1) / t, momp, P, batch, frozen_d));   // :29
+        SBTV_TRY(objective_of_x(frozen_d, momp));
         SBTV_TRY(fetch());
         bool changed = false;
         for (int b = 0; b < batch; ++b) {
@@ -464,7 +504,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     // X <- |X + gam (prox - X)/lamb - gam gradF + sqrt(2 gam) Z|  (:80-81,160-161).  With the device generator the
     // normals are drawn inside the step kernel (no Z array is written or read); injected noise goes through Z.
     // The step kernel also re-arms the prox control blocks for the cold-start prox that always follows it.
-    const ProxArm arm{pp.ctrl, lam_d, op->chambolleit, 1e-3, 0.249};
+    const ProxArm arm{pp.ctrl, lam_d, op->chambolleit, 1e-3, 0.249, nullptr};
     auto myula = [&](bool in_graph) -> int {
         if (noise) {
             SBTV_TRY(next_noise());

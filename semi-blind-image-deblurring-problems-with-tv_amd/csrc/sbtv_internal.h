@@ -147,6 +147,7 @@ struct ProxArm {
     const double *lambda;       // [batch] (device)
     int maxiter;
     double tol, tau;
+    const int *frozen;          // optional per-image flag: armed as done (FISTA batches)
 };
 
 // hipGraph replay of launch-bound iteration bodies (ctx.hip)
@@ -248,8 +249,8 @@ int reduce_partials(sbtv_ctx *ctx, const double *partials, int nvec, int n, doub
 int ew_blocks(size_t P);
 // out4_dev[b*4 + {0,1,2,3}] = sum (a-c)^2, sum a^2, sum c^2, max a
 int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev);
-int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot);
-int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, const double *coef_dev,
+int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot, const ProxArm *arm = nullptr, int batch = 0);
+int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, double coef,
                    double *partials, size_t P, int batch, const int *frozen);
 // Z == nullptr: the normals are drawn in the kernel from `rng` (the numbers randn_kernel would have stored)
 int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
