@@ -646,32 +646,38 @@ int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
     return 0;
 }
 
-static inline int cols_nseq(int n1, int N) {
-    const int T = n1 / 8;
+// columns per workgroup: as many as fit 256 threads, but small problems (fewer workgroups than CUs) are bound by
+// the latency of one workgroup, not by throughput, so they get fewer columns per workgroup and more workgroups
+static inline int cols_nseq(const FftPlan &pl) {
+    const int T = pl.n1 / 8;
     int nseq = COLS_THREADS / T;
     if (nseq < 1) nseq = 1;
-    if (nseq > N) nseq = N;
+    if (nseq > pl.N) nseq = pl.N;
+    // (never below one full wave per workgroup: the fused bookkeeping epilogue needs at least 6 threads)
+    // The choice depends on the image size only, never on the batch: image k of a batch is then computed exactly
+    // like image k alone (same partial-sum grouping), bit for bit.
+    while (nseq > 1 && (nseq / 2) * T >= 64 && pl.N / nseq < 256) nseq >>= 1;
     return nseq;
 }
 
 template <int L>
 static void launch_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S,
                             const int *frozen) {
-    const int nseq = cols_nseq(pl.n1, pl.N);
+    const int nseq = cols_nseq(pl);
     hipLaunchKernelGGL(fft_cols_fwd_kernel<L>, dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0, ctx->stream,
                        x, add, S, pl.tw_n1, pl.tw_M, pl.N, frozen);
 }
 template <int L>
 static void launch_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale,
                             const int *frozen) {
-    const int nseq = cols_nseq(pl.n1, pl.N);
+    const int nseq = cols_nseq(pl);
     hipLaunchKernelGGL((fft_cols_inv_kernel<L, false>), dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0,
                        ctx->stream, S, x, pl.tw_n1, pl.tw_M, pl.N, scale, frozen, ColsPost{});
 }
 template <int L>
 static void launch_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale,
                                  const int *frozen, const ColsPost &post) {
-    const int nseq = cols_nseq(pl.n1, pl.N);
+    const int nseq = cols_nseq(pl);
     hipLaunchKernelGGL((fft_cols_inv_kernel<L, true>), dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0,
                        ctx->stream, S, x, pl.tw_n1, pl.tw_M, pl.N, scale, frozen, post);
 }
@@ -714,7 +720,7 @@ int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x
 int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale) {
     return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
 }
-int fft_cols_blocks(const FftPlan &pl) { return pl.N / cols_nseq(pl.n1, pl.N); }
+int fft_cols_blocks(const FftPlan &pl) { return pl.N / cols_nseq(pl); }
 int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
                       const ColsPost &post) {
     const int L = ilog2(pl.n1);
@@ -727,15 +733,20 @@ int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double
 
 // rows per workgroup of the row pass: 4 (64-byte segments) from N = 512 on, 8 below; N = 2048 may use
 // 2 (SBTV_ROWS_RK=2: 512-thread workgroups, two per CU so load / FFT / store phases overlap)
-static inline int rows_rk(int N) {
+static inline int rows_rk(const FftPlan &pl) {
     static const int rk2048 = [] {
         const char *e = getenv("SBTV_ROWS_RK");
         return (e && atoi(e) == 2) ? 2 : 4;
     }();
+    const int N = pl.N;
     if (N == 2048) return rk2048;
-    return (N >= 512) ? 4 : 8;
+    const int rk = (N >= 512) ? 4 : 8;
+    // small images: fewer rows per workgroup (more workgroups) when the grid of ONE image would leave most CUs
+    // idle; a function of the image size only (see cols_nseq)
+    const int small = (N == 512) ? 1 : (N == 256) ? 2 : rk;
+    return (pl.n1 / rk < 128) ? small : rk;
 }
-int fft_rows_blocks(const FftPlan &pl) { return pl.n1 / rows_rk(pl.N); }
+int fft_rows_blocks(const FftPlan &pl) { return pl.n1 / rows_rk(pl); }
 
 template <int L, int RK>
 static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
@@ -775,10 +786,13 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     if (L > 11) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 2048");
     if (pl.N >= 512) {
         switch (L) {
-            case 9: launch_rows<9, 4>(ctx, pl, p); break;
+            case 9:
+                if (rows_rk(pl) == 1) launch_rows<9, 1>(ctx, pl, p);
+                else launch_rows<9, 4>(ctx, pl, p);
+                break;
             case 10: launch_rows<10, 4>(ctx, pl, p); break;
             case 11:
-                if (rows_rk(pl.N) == 2) launch_rows<11, 2>(ctx, pl, p);
+                if (rows_rk(pl) == 2) launch_rows<11, 2>(ctx, pl, p);
                 else launch_rows<11, 4>(ctx, pl, p);
                 break;
             default: break;
@@ -789,7 +803,10 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
             case 5: launch_rows<5, 8>(ctx, pl, p); break;
             case 6: launch_rows<6, 8>(ctx, pl, p); break;
             case 7: launch_rows<7, 8>(ctx, pl, p); break;
-            case 8: launch_rows<8, 8>(ctx, pl, p); break;
+            case 8:
+                if (rows_rk(pl) == 2) launch_rows<8, 2>(ctx, pl, p);
+                else launch_rows<8, 8>(ctx, pl, p);
+                break;
             default: return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be >= 16");
         }
     }
