@@ -4,6 +4,13 @@
   python tools/bench_sapg.py --config 4   # 8 independent 1024x1024 images, Laplace PSF (one GPU's share of 64)
   python tools/bench_sapg.py --config 5   # 4 MYULA chains on one 2048x2048 image, Gaussian PSF (share of 32)
   python tools/bench_sapg.py --config 3   # FISTA + TV prox, 2048x2048, Moffat PSF
+
+Under torch.distributed.run the same script runs the whole configuration, one rank per GPU:
+  config 4: 64 images sharded over the ranks (image i -> rank i mod world), no data-path collective;
+  config 5: 32 chains on one image split over the ranks (disjoint Philox streams through chain_offset), ONE
+            all-reduce of 5 doubles per SAPG iteration (sbtv.dist.make_allreduce_fn = RCCL with the nccl backend).
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_sapg.py --config 5
+  (--backend gloo --all-ranks-on-device0 rehearses the multi-rank path on a one-GPU box)
 """
 import argparse
 import os
@@ -43,7 +50,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=5)
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--total", type=int, default=0, help="images (config 4, default 64) / chains (config 5, default 32) "
+                                                         "over all ranks; single process default: one GPU's share")
+    ap.add_argument("--backend", default=None)
+    ap.add_argument("--all-ranks-on-device0", action="store_true")
     a = ap.parse_args()
+    from sbtv import dist as sd
+    rank, world = sd.init(a.backend)
+    local = 0 if a.all_ranks_on_device0 else int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = sbtv.Context(local)
+    dev = f"cuda:{local}"
     rng = np.random.default_rng(1)
     if a.config == 3:
         x = image(2048)
@@ -59,30 +75,46 @@ def main():
               f"({1e3 * dt / (a.iters - 1):.3f} ms/iteration), objective {out[1][0]:.4e} -> {out[1][-1]:.4e}")
         return
     if a.config == 4:
-        kind, size, nimg, share = "laplace", 1024, 8, False
+        kind, size, share = "laplace", 1024, False
+        total = a.total or (64 if world > 1 else 8)
+        nimg, first = len(sd.shard(total)), 0
     else:
-        kind, size, nimg, share = "gaussian", 2048, 4, True
+        kind, size, share = "gaussian", 2048, True
+        total = a.total or (32 if world > 1 else 4)
+        nimg, first = sd.split_chains(total)
     x = image(size)
-    st = sbtv.demo_setup(kind, x, rng.standard_normal(x.shape), evMax=0.99)
+    st = sbtv.demo_setup(kind, x, rng.standard_normal(x.shape), evMax=0.99, ctx=ctx)
     samples, warmup = a.iters + 1, 0
     op, c = op_struct(kind, st, samples, warmup, 2)
     fn = sbtv.SAPG_algorithm_laplace if kind == "laplace" else sbtv.SAPG_algorithm_Guassian
     if share:
-        op["chains"] = nimg
-        y = sbtv.to_device(st["y"])
-        kw = dict(share_gradients=True)
+        op["chains"], op["chain_offset"] = nimg, first
+        y = sbtv.to_device(st["y"], dev)
+        kw = dict(share_gradients=True, reduce_fn=sd.make_allreduce_fn(), ctx=ctx)
     else:
-        y = sbtv.to_device(np.stack([st["y"]] * nimg))
-        kw = {}
+        y = sbtv.to_device(np.stack([st["y"]] * nimg), dev)
+        kw = dict(ctx=ctx)
     op2 = dict(op, samples=3)
     fn(y, op2, c, **kw)                      # warm-up (workspaces, twiddles)
+    sd.barrier()
     t0 = time.perf_counter()
     out = fn(y, op, c, **kw)
+    ctx.sync()
+    sd.barrier()
     dt = time.perf_counter() - t0
     it = samples - 1
-    print(f"config {a.config}: SAPG {kind}, {nimg} x {size}^2 {'chains on one image' if share else 'images'}: "
-          f"{it / dt:.2f} SAPG iterations/s per GPU ({1e3 * dt / it:.2f} ms/iteration, "
-          f"{1e3 * dt / it / nimg:.2f} ms per image-iteration)")
+    thetas = [float(np.ravel(r["thetas"])[-1]) for r in out[-1]] if isinstance(out[-1], list) else [float(out[-1]["thetas"][-1])]
+    allth = sd.gather_objects(thetas)
+    if rank == 0:
+        unit = "chains on one image" if share else "images"
+        print(f"config {a.config}: SAPG {kind}, {total} x {size}^2 {unit} on {world} rank(s) ({nimg} per rank): "
+              f"{it / dt:.2f} SAPG iterations/s ({1e3 * dt / it:.2f} ms/iteration, "
+              f"{1e3 * dt / it / nimg:.2f} ms per local image-iteration), "
+              f"{total * it / dt:.0f} image-iterations/s in total")
+        if share:
+            flat = [t for part in allth for t in part]
+            print(f"  last theta of every chain equal across ranks: {max(flat) - min(flat) == 0.0} ({flat[0]:.6g})")
+    sd.barrier()
 
 
 if __name__ == "__main__":
