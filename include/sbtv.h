@@ -12,7 +12,7 @@
  * Conventions
  *   - all image buffers are IEEE double, column-major (MATLAB layout):
  *     element (i,j) of image b lives at  buf[b*M*N + j*M + i],  M rows, N cols.
- *   - M and N must be powers of two, 16 <= M <= 4096, 16 <= N <= 2048, for every
+ *   - M and N must be powers of two, 16 <= M <= 4096, 16 <= N <= 4096, for every
  *     entry point that applies the blur operator (hand-written radix-2^k FFT).
  *     The TV entry points (prox, TVnorm) accept any M >= 2, N >= 2 (even M takes
  *     the fused 16-byte-per-lane kernels, odd M a scalar one-iteration kernel).

@@ -634,8 +634,8 @@ __global__ __launch_bounds__(64) void psf_spectrum_kernel(const double *__restri
 // host side
 // ---------------------------------------------------------------------------
 int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
-    if (!is_pow2(M) || !is_pow2(N) || M < 16 || N < 16 || M > 4096 || N > 2048)
-        return fail(ctx, SBTV_ERR_SIZE, "blur operator: M and N must be powers of two, 16 <= M <= 4096, 16 <= N <= 2048");
+    if (!is_pow2(M) || !is_pow2(N) || M < 16 || N < 16 || M > 4096 || N > 4096)
+        return fail(ctx, SBTV_ERR_SIZE, "blur operator: M and N must be powers of two, 16 <= M, N <= 4096");
     pl->M = M;
     pl->N = N;
     pl->batch = batch;
@@ -739,6 +739,7 @@ static inline int rows_rk(const FftPlan &pl) {
         return (e && atoi(e) == 2) ? 2 : 4;
     }();
     const int N = pl.N;
+    if (N == 4096) return 2;                 // two 4096-point rows fill the LDS exchange buffer (128 KB)
     if (N == 2048) return rk2048;
     const int rk = (N >= 512) ? 4 : 8;
     // small images: fewer rows per workgroup (more workgroups) when the grid of ONE image would leave most CUs
@@ -783,7 +784,7 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.op = a.op;
     p.shared_spec = a.shared_spec;
     const int L = ilog2(pl.N);
-    if (L > 11) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 2048");
+    if (L > 12) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 4096");
     if (pl.N >= 512) {
         switch (L) {
             case 9:
@@ -795,6 +796,7 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
                 if (rows_rk(pl) == 2) launch_rows<11, 2>(ctx, pl, p);
                 else launch_rows<11, 4>(ctx, pl, p);
                 break;
+            case 12: launch_rows<12, 2>(ctx, pl, p); break;
             default: break;
         }
     } else {

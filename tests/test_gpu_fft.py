@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("shape", [(16, 16), (16, 64), (32, 16), (64, 128), (128, 32), (256, 256), (512, 1024),
-                                   (1024, 512), (2048, 2048), (4096, 64), (4096, 2048)])   # last: the largest supported size
+                                   (1024, 512), (2048, 2048), (4096, 64), (4096, 2048), (16, 4096),
+                                   (4096, 4096)])   # last: the largest supported size
 def test_rfft2_matches_numpy(ctx, shape):
     import sbtv
     M, N = shape
@@ -100,18 +101,18 @@ def test_full_size_linearity_and_roundtrip(ctx):
     assert float((w - z).abs().max()) < 1e-10
 
 
-def test_maximum_size_operator_4096x2048(ctx):
-    """The largest image the blur operator accepts (M = 4096, N = 2048, sbtv.h): A against the spatial 7x7 circular
+@pytest.mark.parametrize("M,N", [(4096, 2048), (4096, 4096)])
+def test_maximum_size_operator(ctx, M, N):
+    """The largest images the blur operator accepts (M, N <= 4096, sbtv.h): A against the spatial 7x7 circular
     sum on a sample of pixels, the adjoint identity and invLS(mu) as the inverse of A'A + mu I."""
     import sbtv
-    M, N = 4096, 2048
     rng = np.random.default_rng(5)
     x, z = rng.uniform(0, 255, (M, N)), rng.standard_normal((M, N))
     taps = sbtv.Gaussian_psf(7, 0.4, 0.3)
     A = sbtv.BlurOperator(taps)
     ax, atz = A.A(x), A.AT(z)
     assert float(np.sum(ax * z)) == pytest.approx(float(np.sum(x * atz)), rel=1e-11)
-    for i, j in [(0, 0), (1, 5), (4095, 2047), (2048, 1024), (3, 2046), (4093, 2)]:
+    for i, j in [(0, 0), (1, 5), (M - 1, N - 1), (M // 2, N // 2), (3, N - 2), (M - 3, 2)]:
         ref = sum(taps[m, n] * x[(i - m) % M, (j - n) % N] for m in range(7) for n in range(7))
         assert ax[i, j] == pytest.approx(ref, rel=1e-12)
     mu = 0.05
@@ -119,3 +120,5 @@ def test_maximum_size_operator_4096x2048(ctx):
     np.testing.assert_allclose(A.invLS(r, mu), x, rtol=0, atol=1e-9)
     with pytest.raises(sbtv.SbtvError):
         A.A(np.zeros((8192, 16)))                       # beyond the supported size
+    with pytest.raises(sbtv.SbtvError):
+        A.A(np.zeros((16, 8192)))
