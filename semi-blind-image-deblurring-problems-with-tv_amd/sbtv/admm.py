@@ -13,10 +13,10 @@ from .operators import BlurOperator, _Adjoint, _InvLS
 from .tv import _parse_varargin
 
 _CSALSA_OPTIONS = {"P", "PT", "PSI", "PHI", "TVINITIALIZATION", "TVITERS", "STOPCRITERION", "TOLERANCEA", "MAXITERA",
-                   "INITIALIZATION", "TRUE_X", "AT", "LS", "VERBOSE", "CONTINUATIONFACTOR", "EPSILON"}
+                   "INITIALIZATION", "TRUE_X", "AT", "LS", "VERBOSE", "CONTINUATIONFACTOR", "EPSILON", "SEED"}
 _CORAL_OPTIONS = {"W", "WT", "P1", "P1T", "P2", "P2T", "PSI1", "PHI1", "TVINITIALIZATION1", "TVITERS1", "PSI2", "PHI2",
                   "TVINITIALIZATION2", "TVITERS2", "MU1", "MU2", "STOPCRITERION", "TOLERANCEA", "INNERITERS",
-                  "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS"}
+                  "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS", "SEED"}
 
 _vp = lambda a: a.ctypes.data_as(C.c_void_p)
 
@@ -42,7 +42,12 @@ def _common(y, A, opts, ctx, default_stop):
         so.initialization = 33333
     else:
         so.initialization = int(init)
-        if so.initialization not in (0, 2):
+        if so.initialization == 1:
+            # random start (CSALSA_v2.m:382, CoRAL_v2.m:331): NumPy normals (option 'SEED'), handed over as a given x
+            x0 = np.random.default_rng(int(opts.get("SEED", 0))).standard_normal((yi.B, yi.M, yi.N))
+            xinit = L.Images(L.to_device(x0, yi.t.device) if yi.torch else x0)
+            so.initialization = 33333
+        elif so.initialization not in (0, 2):
             raise L.SbtvError(-7, "Unknown 'Initialization' option")
     true = opts.get("TRUE_X", None)
     ti = L.Images(true) if true is not None else None

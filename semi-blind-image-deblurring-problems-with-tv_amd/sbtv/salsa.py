@@ -11,7 +11,7 @@ from .operators import BlurOperator, _Adjoint, _InvLS
 from .tv import _parse_varargin
 
 _OPTIONS = {"P", "PT", "PSI", "PHI", "TVINITIALIZATION", "TVITERS", "MU", "STOPCRITERION", "TOLERANCEA",
-            "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS"}
+            "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS", "SEED"}
 
 
 def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
@@ -69,7 +69,14 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
         so.initialization = 33333                                                             # :221
     else:
         so.initialization = int(init)
-        if so.initialization not in (0, 2):
+        if so.initialization == 1:
+            # x = randn(size(AT(zeros(size(y)))))  (:371).  MATLAB's stream cannot be reproduced: the start image is
+            # drawn with NumPy (seed via the extra option 'SEED', default 0) and handed over like a given initial x
+            rng = np.random.default_rng(int(opts.get("SEED", 0)))
+            x0 = rng.standard_normal((yi.B, yi.M, yi.N))
+            xinit = L.Images(L.to_device(x0, yi.t.device) if yi.torch else x0)
+            so.initialization = 33333
+        elif so.initialization not in (0, 2):
             raise L.SbtvError(-7, "Unknown 'Initialization' option")                         # :382
     true = opts.get("TRUE_X", None)
     ti = L.Images(true) if true is not None else None

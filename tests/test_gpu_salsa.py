@@ -220,3 +220,26 @@ def test_salsa_2048_device_resident_properties(ctx, man512):
     xh = sbtv.to_host(xg)
     assert o.PSNR(x, xh) > o.PSNR(x, st["y"]) + 1.0
     assert sbtv.PSNR(xd, xg) == pytest.approx(o.PSNR(x, xh), abs=1e-9)
+
+
+def test_salsa_random_initialization(ctx):
+    """'INITIALIZATION', 1 (SALSA_v2.m:371: x = randn(...)): the start image comes from NumPy (MATLAB's stream is not
+    reproducible), so parity is against the oracle started from the same array."""
+    import sbtv
+    import sbtv_oracle as o
+    x = synth_image(64, 64, 9)
+    st = _problem(x)
+    theta, s2 = 0.03, st["sigma"] ** 2
+    mu = theta / 10
+    A = sbtv.BlurOperator(sbtv.psf_family("gaussian", 7, st["p_true"])[0])
+    got = sbtv.SALSA_v2(st["y"], A, theta * s2, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", x, "ToleranceA", 1e-5,
+                        "MAXITERA", 40, "TVINITIALIZATION", 1, "TViters", 10, "INITIALIZATION", 1, "SEED", 3)
+    x0 = np.random.default_rng(3).standard_normal((1, 64, 64))[0]
+    m, p = st["model"], st["p_true"]
+    H2 = np.abs(m.H_FFT(*p)) ** 2
+    ref = o.SALSA_v2(st["y"], lambda z: m.A(z, *p), theta * s2, mu=mu, AT=lambda z: m.AT(z, *p),
+                     invLS=lambda r: np.real(o.ifft2(o.fft2(r) / (H2 + mu))), true_x=x, tolA=1e-5, maxiter=40, TViters=10,
+                     initialization=x0)
+    assert len(got[3]) == len(ref["objective"])
+    np.testing.assert_allclose(got[3], ref["objective"], rtol=1e-9)
+    assert np.max(np.abs(got[0] - ref["x"])) < 1e-6
