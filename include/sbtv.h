@@ -261,6 +261,17 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                         double *logpi_wu, double *gx, double *grads, double *eb,
                         double *x_last, sbtv_allreduce_fn reduce_fn, void *reduce_user, int flags);
 
+/* Plain MYULA chain at fixed parameters: replaces  xMAP = myula(op, im)  (SALSA/myula.m:1-22) with the closures
+ * of SALSA/run_deblur_tv.m:126,131:  proxG(x,lambda,theta) = chambolle_prox_TV_stop(x,'lambda',lambda*theta,
+ * 'maxiter',chambolleit),  gradF(x) = AT(A x - y)/sigma2.  x starts at y; samples-2 steps
+ *   x = (1 - gamma/lambda) x - gamma (gradF(x) - prox/lambda) + sqrt(2 gamma) z        (:16, no abs())
+ * theta[batch], sigma2[batch] host arrays; noise: NULL (device Philox, stream chain_offset + b) or
+ * (samples-2)*batch*M*N doubles, step-major.  x_out: the last sample of every chain. */
+int sbtv_myula(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const double *taps, int taille,
+               double lambda, double gamma, const double *theta, const double *sigma2, int samples,
+               int chambolleit, unsigned long long seed, int chain_offset, const double *noise,
+               double *x_out, int flags);
+
 /* ---- a-9: largest eigenvalue of A'A by power iteration --------------------
  * Replaces max_eigenval(A,At,params,im_size,tol,max_iter,verbose)
  * (utils/max_eigenval_Gaussian_Moffat.m:1-27, max_eigenval_Laplace.m:1-28).

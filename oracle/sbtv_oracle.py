@@ -856,6 +856,19 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
                 Xlast_sample=X, prox_last=prox)
 
 
+def myula(op, im, randn):
+    """SALSA/myula.m:1-22 (plain MYULA chain at fixed theta / PSF parameter, the last sample is returned).
+    op: dict with y, lambda, gamma, theta_op, tau_op, samples, gradF(x, tau), proxG(x, lambda, theta)
+    (closures as in SALSA/run_deblur_tv.m:126,131); randn(shape) supplies z (MATLAB's stream is unpinned)."""
+    x = np.array(op["y"], dtype=np.float64)                  # :3,11
+    lam, gam, theta, tau = op["lambda"], op["gamma"], op["theta_op"], op["tau_op"]
+    for ii in range(2, int(op["samples"])):                  # ii = 2 : sample-1   (:13)
+        z = randn(im.shape)                                  # :14
+        prox = op["proxG"](x, lam, theta)                    # :15
+        x = (1 - gam / lam) * x - gam * (op["gradF"](x, tau) - prox / lam) + math.sqrt(2 * gam) * z   # :16
+    return x
+
+
 def salsa_from_estimates(setup, theta_EB, p_EB, sigma2_EB, tol=1e-5, outeriters=500, TViters=10, max_time=None):
     """run_Gaussian_demo.m:210-242 (and the Moffat / Laplace twins)."""
     model = setup["model"]

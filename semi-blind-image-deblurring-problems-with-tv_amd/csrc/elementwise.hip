@@ -175,9 +175,59 @@ __global__ __launch_bounds__(EWB) void myula_step_kernel(double *__restrict__ X,
     }
 }
 
+// ---- plain MYULA chain (SALSA/myula.m:16): no abs(), the reference's own grouping of the terms
+//   x = (1 - gam/lamb) x - gam (grad/sigma2 - prox/lamb) + sqrt(2 gam) z
+__global__ __launch_bounds__(EWB) void myula_plain_kernel(double *__restrict__ X, const double *__restrict__ prox,
+                                                           const double *__restrict__ grad,
+                                                           const double *__restrict__ Z,
+                                                           const double *__restrict__ sigma2, double gam, double lamb,
+                                                           double sq2g, size_t P, RngArgs rng, ProxArm arm) {
+    const int b = blockIdx.y;
+    if (arm.ctrl && blockIdx.x == 0 && threadIdx.x == 0) {
+        ProxCtrl c = arm.ctrl[b];
+        c.k = 0;
+        c.done = 0;
+        c.cur = 0;
+        c.maxiter = arm.maxiter;
+        c.redo = 0;
+        c.f_valid = 0;
+        c.err = 0.0;
+        c.lambda = arm.lambda[b];
+        c.tol = arm.tol;
+        c.tau = arm.tau;
+        arm.ctrl[b] = c;
+    }
+    const size_t base = (size_t)b * P;
+    const double s2 = sigma2[b], keep = 1.0 - gam / lamb;
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P / 2; q += (size_t)gridDim.x * EWB) {
+        const size_t o = base + 2 * q;
+        const double2 xv = *reinterpret_cast<const double2 *>(X + o);
+        const double2 pv = *reinterpret_cast<const double2 *>(prox + o);
+        const double2 gv = *reinterpret_cast<const double2 *>(grad + o);
+        const double2 zv = Z ? *reinterpret_cast<const double2 *>(Z + o)
+                             : philox_normal_pair(q, rng.step, rng.chain0 + (unsigned)b, rng.seed);
+        double2 r;
+        r.x = (keep * xv.x - gam * (gv.x / s2 - pv.x / lamb)) + sq2g * zv.x;
+        r.y = (keep * xv.y - gam * (gv.y / s2 - pv.y / lamb)) + sq2g * zv.y;
+        *reinterpret_cast<double2 *>(X + o) = r;
+    }
+}
+
 // --------------------------------------------------------------------------
 // host wrappers
 // --------------------------------------------------------------------------
+int myula_plain_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
+                     const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng,
+                     const ProxArm *arm) {
+    if (!Z && !rng) return fail(ctx, SBTV_ERR_BADARG, "myula_plain_step: neither a noise array nor generator arguments");
+    const RngArgs r = rng ? *rng : RngArgs{0ull, 0u, 0u, nullptr};
+    const ProxArm pa = arm ? *arm : ProxArm{nullptr, nullptr, 0, 0.0, 0.0, nullptr};
+    hipLaunchKernelGGL(myula_plain_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, X, prox, grad, Z,
+                       sigma2_dev, gam, lamb, sqrt(2 * gam), P, r, pa);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev) {
     const int nb = ew_blocks(P);
     double *partials = nullptr;

@@ -343,6 +343,87 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
 }
 
 // ---------------------------------------------------------------------------
+// a-6: plain MYULA chain at fixed parameters (SALSA/myula.m:1-22)
+// ---------------------------------------------------------------------------
+int sbtv_myula(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const double *taps, int taille, double lambda,
+               double gamma, const double *theta, const double *sigma2, int samples, int chambolleit,
+               unsigned long long seed, int chain_offset, const double *noise, double *x_out, int flags) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    if (!y || !taps || !theta || !sigma2 || !x_out || batch < 1 || samples < 2 || !(lambda > 0.0) || !(gamma > 0.0) ||
+        chain_offset < 0)
+        return fail(ctx, SBTV_ERR_BADARG, "myula: bad arguments");
+    if (chambolleit <= 0) return fail(ctx, SBTV_ERR_MAXITER, "myula: chambolleit must be positive");
+    if (taille < 1 || taille > 15 || taille > M || taille > N) return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    FftPlan fp;
+    SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
+    ProxPlan pp;
+    SBTV_TRY(prox_plan(ctx, M, N, batch, &pp));
+    const size_t P = (size_t)M * N, cnt = P * batch, spec = (size_t)(fp.n1 + 1) * N;
+    const double *yd = nullptr;
+    SBTV_TRY(stage_in(ctx, "myula.y", y, cnt, flags, &yd));
+    const bool noise_host = noise && !(flags & SBTV_DEVICE_PTRS);
+    double *X = nullptr, *prox = nullptr, *grad = nullptr, *Z = nullptr, *par = nullptr, *acc = nullptr;
+    double2 *S = nullptr, *Hs = nullptr, *Ys = nullptr;
+    SBTV_TRY(stage_out_buf(ctx, "myula.X", x_out, cnt, flags, &X));
+    SBTV_TRY(ws_get_t(ctx, "myula.prox", cnt, &prox));
+    SBTV_TRY(ws_get_t(ctx, "myula.grad", cnt, &grad));
+    if (noise_host) SBTV_TRY(ws_get_t(ctx, "myula.Z", cnt, &Z));
+    SBTV_TRY(ws_get_t(ctx, "myula.S", cnt / 2, &S));
+    SBTV_TRY(ws_get_t(ctx, "myula.H", spec * batch, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "myula.Y", spec * batch, &Ys));
+    SBTV_TRY(ws_get_t(ctx, "myula.acc", (size_t)batch * 3 * fft_rows_blocks(fp), &acc));
+    const size_t t2 = (size_t)taille * taille, npar = t2 * batch + 2 * (size_t)batch;
+    SBTV_TRY(ws_get_t(ctx, "myula.par", npar, &par));      // [taps | lambda*theta | sigma2]
+    double *taps_d = par, *lam_d = par + t2 * batch, *sig_d = lam_d + batch;
+    std::vector<double> hpar(npar);
+    for (size_t q = 0; q < t2 * batch; ++q) hpar[q] = taps[q];
+    for (int b = 0; b < batch; ++b) {
+        hpar[t2 * batch + b] = lambda * theta[b];           // proxG(x, lambda, theta)   (run_deblur_tv.m:126)
+        hpar[t2 * batch + batch + b] = sigma2[b];
+    }
+    SBTV_HIP(ctx, hipMemcpyAsync(par, hpar.data(), sizeof(double) * npar, hipMemcpyHostToDevice, ctx->stream));
+    SBTV_TRY(psf_spectrum(ctx, fp, taps_d, taille, Hs));
+    {
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        SBTV_TRY(fft_cols_fwd(ctx, fp, yd, nullptr, S));
+        SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+        SBTV_TRY(spec_unpack(ctx, fp, S, Ys));
+    }
+    SBTV_HIP(ctx, hipMemcpyAsync(X, yd, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));   // x = op.y  (:3,11)
+    const double inv_scale = 1.0 / ((double)fp.n1 * N);
+    SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, chambolleit, 1e-3, 0.249, false, nullptr));
+    const ProxArm arm{pp.ctrl, lam_d, chambolleit, 1e-3, 0.249, nullptr};
+    for (int ii = 2; ii <= samples - 1; ++ii) {             // :13
+        const size_t step = (size_t)(ii - 2);
+        SBTV_TRY(prox_iterate(ctx, pp, X, chambolleit, prox, true));                         // :15
+        RowsArgs a{};                                       // gradF = AT(A x - y) / sigma2   (run_deblur_tv.m:131)
+        a.dir_fwd = 1;
+        a.dir_inv = 1;
+        a.op = OP_GRADF;
+        a.H = Hs;
+        a.Y = Ys;
+        a.acc = acc;
+        SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+        SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+        SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+        const double *zd = nullptr;
+        if (noise_host) {
+            SBTV_HIP(ctx, hipMemcpyAsync(Z, noise + step * cnt, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
+            zd = Z;
+        } else if (noise) {
+            zd = noise + step * cnt;
+        }
+        const RngArgs r{seed, (unsigned)step, (unsigned)chain_offset, nullptr};
+        SBTV_TRY(myula_plain_step(ctx, X, prox, grad, zd, sig_d, gamma, lambda, P, batch, &r, &arm));   // :16
+    }
+    SBTV_TRY(stage_out_copy(ctx, x_out, X, cnt, flags));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // a-5 / a-6: SAPG with a MYULA kernel
 // ---------------------------------------------------------------------------
 int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const sbtv_sapg_opts *op,

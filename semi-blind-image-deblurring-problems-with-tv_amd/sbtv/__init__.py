@@ -15,11 +15,11 @@ from .diagnostics import ssim, save_results, load_results, plot_traces, save_ima
 from .metrics import PSNR, MSE
 from .fista import my_fista, my_deblur_fista, Psi_TV
 from .sapg import (SAPG_algorithm_Guassian, SAPG_algorithm_moffat, SAPG_algorithm_laplace, max_eigenval,
-                   demo_setup)
+                   demo_setup, myula)
 
 __all__ = [
     "my_fista", "my_deblur_fista", "Psi_TV", "SAPG_algorithm_Guassian", "SAPG_algorithm_moffat",
-    "SAPG_algorithm_laplace", "max_eigenval", "demo_setup",
+    "SAPG_algorithm_laplace", "max_eigenval", "demo_setup", "myula",
     "Context", "SbtvError", "default_context", "load_library", "to_device", "to_host", "LIB_PATH",
     "chambolle_prox_TV_stop", "TVnorm", "BlurOperator", "A_wrapper", "Gaussian_psf", "psf_gaussian",
     "psf_moffat", "psf_laplace", "psf_family", "rfft2_packed", "unpack_half_spectrum", "SALSA_v2", "PSNR", "MSE",

@@ -89,6 +89,7 @@ SIGNATURES = {
     "sbtv_fista_tv": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _D, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P, _I]),
     "sbtv_SAPG_algorithm": (_I, [_P, _P, _I, _I, _I, C.POINTER(sbtv_sapg_opts), _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                  _P, _P, ALLREDUCE_FN, _P, _I]),
+    "sbtv_myula": (_I, [_P, _P, _I, _I, _I, _P, _I, _D, _D, _P, _P, _I, _I, C.c_ulonglong, _I, _P, _P, _I]),
     "sbtv_max_eigenval": (_I, [_P, _P, _I, _P, _I, _I, _D, _I, _P, _P, _I]),
     "sbtv_PSNR": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
     "sbtv_MSE": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),

@@ -200,3 +200,40 @@ def SAPG_algorithm_laplace(y, op, c=None, **kw):
     c = c or dict(theta=0.01, b=100.0, sigma=1e4, lam=1.0, gam=1.0)
     res = _sapg("laplace", y, op, c, **kw)
     return _unpack("laplace", res, len(res) > 1)
+
+
+def myula(op, im=None, noise=None, ctx=None):
+    """xMAP = myula(op, im)  (SALSA/myula.m:1-22): the plain MYULA chain at fixed theta / PSF, last sample returned.
+
+    op: dict / object with y, lambda, gamma, theta_op, samples as in the reference, plus what the closures
+    op.proxG / op.gradF of SALSA/run_deblur_tv.m:126,131 are built from: `A` (the sbtv.BlurOperator at tau_op),
+    `sigma2` (or `sigma`), `chambolleit` (25).  `im` is only used for its shape in the reference and is ignored.
+    noise: optional (samples-2, [B,] M, N) array instead of the device Philox stream (op.seed, op.chain_offset)."""
+    ctx = ctx or L.default_context()
+    A = _get(op, "A")
+    if not isinstance(A, BlurOperator):
+        raise TypeError("op.A must be the sbtv.BlurOperator the closures op.gradF / op.proxG are built from")
+    yi = L.Images(_get(op, "y"))
+    B, M, N = yi.B, yi.M, yi.N
+    s2 = _get(op, "sigma2")
+    if s2 is None:
+        s2 = np.asarray(_get(op, "sigma"), dtype=np.float64) ** 2
+    keep = [L.dvec(_get(op, "theta_op"), B), L.dvec(s2, B)]
+    taps = A._cm(B)
+    xo = L.empty_like_images(yi)
+    nz_ptr, nz_keep = None, None
+    if noise is not None:
+        if L._is_torch(noise):
+            nz_keep, nz_ptr = noise, C.c_void_p(noise.data_ptr())
+        else:
+            a = np.asarray(noise, dtype=np.float64)
+            if a.ndim == 3:
+                a = a[:, None]
+            nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))
+            nz_ptr = nz_keep.ctypes.data_as(C.c_void_p)
+    ctx.check(ctx.lib.sbtv_myula(ctx.h, yi.ptr, M, N, B, taps.ctypes.data_as(C.c_void_p), A.taille,
+                                 float(_get(op, "lambda")), float(_get(op, "gamma")), keep[0][1], keep[1][1],
+                                 int(_get(op, "samples")), int(_get(op, "chambolleit", 25)), int(_get(op, "seed", 1)),
+                                 int(_get(op, "chain_offset", 0)), nz_ptr, xo.ptr, yi.flags), yi.flags)
+    y = _get(op, "y")
+    return L.images_result(xo, (y.dim() == 2) if yi.torch else yi.squeeze)

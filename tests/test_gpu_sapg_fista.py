@@ -346,3 +346,37 @@ def test_sapg_config5_shape_shared_chains_2048(ctx, man512):
     for key in ("grad_theta", "grad_w1", "grad_w2", "grad_sigma"):
         mean1 = np.mean([s[key][1] for s in singles])
         assert shared[0][key][1] == pytest.approx(mean1, rel=1e-12), key
+
+
+def test_plain_myula_chain_matches_oracle(ctx):
+    """SALSA/myula.m: the plain MYULA chain at fixed theta / PSF parameter, with injected noise against the oracle
+    (closures of run_deblur_tv.m:126,131), and with the device generator for reproducibility."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    x = synth_image(M, N, 21)
+    rng = np.random.default_rng(8)
+    st = o.demo_setup("gaussian", x, rng.standard_normal((M, N)), evMax=0.99)
+    m, p, s2 = st["model"], st["p_true"], st["sigma"] ** 2
+    samples, K, theta = 9, 25, 0.02
+    nz = rng.standard_normal((samples - 2, M, N))
+    it = iter(nz)
+    op_ref = dict(y=st["y"], samples=samples, theta_op=theta, tau_op=None, gamma=st["gamma"],
+                  gradF=lambda z, tau: np.real(m.AT(m.A(z, *p) - st["y"], *p) / s2),
+                  proxG=lambda z, lam, th: o.chambolle_prox_TV_stop(z, lam=lam * th, maxiter=K)[0])
+    op_ref["lambda"] = st["lam"]
+    ref = o.myula(op_ref, x, lambda shape: next(it))
+    A = sbtv.BlurOperator(sbtv.psf_family("gaussian", 7, p)[0])
+    op = dict(y=st["y"], samples=samples, theta_op=theta, gamma=st["gamma"], A=A, sigma2=s2, chambolleit=K)
+    op["lambda"] = st["lam"]
+    got = sbtv.myula(op, x, noise=nz)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9)
+    a = sbtv.myula(dict(op, seed=5), x)
+    b = sbtv.myula(dict(op, seed=5), x)
+    c = sbtv.myula(dict(op, seed=6), x)
+    np.testing.assert_array_equal(a, b)
+    assert np.max(np.abs(a - c)) > 1e-3
+    # two chains in one call draw the streams chain_offset + 0 / + 1
+    two = sbtv.myula(dict(op, seed=5, y=np.stack([st["y"], st["y"]])), x)
+    np.testing.assert_array_equal(two[0], a)
+    np.testing.assert_array_equal(two[1], sbtv.myula(dict(op, seed=5, chain_offset=1), x))
