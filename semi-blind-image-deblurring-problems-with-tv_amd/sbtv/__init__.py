@@ -8,7 +8,7 @@ from ._lib import (Context, SbtvError, default_context, load_library, to_device,
                    SBTV_DEVICE_PTRS, SBTV_HOST_PTRS)
 from .tv import chambolle_prox_TV_stop, TVnorm
 from .operators import (BlurOperator, A_wrapper, Gaussian_psf, psf_gaussian, psf_moffat, psf_laplace, psf_family,
-                        rfft2_packed, unpack_half_spectrum)
+                        rfft2_packed, unpack_half_spectrum, conv2c, diffh, diffv)
 from .salsa import SALSA_v2
 from .admm import csalsa, CSALSA_v2, CoRAL, CoRAL_v2
 from .diagnostics import ssim, save_results, load_results, plot_traces, save_image
@@ -23,5 +23,5 @@ __all__ = [
     "Context", "SbtvError", "default_context", "load_library", "to_device", "to_host", "LIB_PATH",
     "chambolle_prox_TV_stop", "TVnorm", "BlurOperator", "A_wrapper", "Gaussian_psf", "psf_gaussian",
     "psf_moffat", "psf_laplace", "psf_family", "rfft2_packed", "unpack_half_spectrum", "SALSA_v2", "PSNR", "MSE",
-    "csalsa", "CSALSA_v2", "CoRAL", "CoRAL_v2", "ssim", "save_results", "load_results", "plot_traces", "save_image",
+    "csalsa", "CSALSA_v2", "CoRAL", "CoRAL_v2", "ssim", "save_results", "load_results", "plot_traces", "save_image", "conv2c", "diffh", "diffv",
 ]

@@ -166,3 +166,35 @@ def unpack_half_spectrum(buf, M, N):
     U[:, 0] = (P + Q) / 2
     U[:, n1] = (P - Q) / 2j
     return U
+
+
+def conv2c(x, h, ctx=None):
+    """y = conv2c(x, h)  (SALSA/conv2c.m:1-50): circular 2-D convolution with the mask origin at floor((1+size)/2).
+
+    Runs on the spectral blur operator (whose mask origin is the top-left tap, utils/resize.m:8): the mask is embedded
+    in a square tap array and the result rotated back by the origin offset.  Needs power-of-two image sizes like the
+    operator; masks up to 15 x 15."""
+    hh = np.atleast_2d(np.asarray(h, dtype=np.float64))
+    mm, nm = hh.shape
+    xi = L.Images(x)
+    if mm > xi.M or nm > xi.N:
+        raise L.SbtvError(-10, "Mask does not fit inside array")                               # conv2c.m:15
+    T = max(mm, nm)
+    taps = np.zeros((T, T))
+    taps[:mm, :nm] = hh
+    out = BlurOperator(taps, ctx=ctx).A(x)
+    mo, no = (1 + mm) // 2 - 1, (1 + nm) // 2 - 1                                              # conv2c.m:19-20
+    if L._is_torch(out):
+        import torch
+        return torch.roll(out, shifts=(-mo, -no), dims=(-2, -1))
+    return np.roll(out, shift=(-mo, -no), axis=(-2, -1))
+
+
+def diffh(x, ctx=None):
+    """sol = diffh(x) = conv2c(x, [0 1 -1])  (SALSA/diffh.m:1-3): x(i,j) - x(i,j-1), circular."""
+    return conv2c(x, np.array([[0.0, 1.0, -1.0]]), ctx=ctx)
+
+
+def diffv(x, ctx=None):
+    """sol = diffv(x) = conv2c(x, [0 1 -1]')  (SALSA/diffv.m:1-3): x(i,j) - x(i-1,j), circular."""
+    return conv2c(x, np.array([[0.0], [1.0], [-1.0]]), ctx=ctx)

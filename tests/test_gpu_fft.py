@@ -122,3 +122,21 @@ def test_maximum_size_operator(ctx, M, N):
         A.A(np.zeros((8192, 16)))                       # beyond the supported size
     with pytest.raises(sbtv.SbtvError):
         A.A(np.zeros((16, 8192)))
+
+
+def test_conv2c_diffh_diffv_match_oracle(ctx):
+    """SALSA/conv2c.m (mask origin at the mask centre) and diffh / diffv through the spectral operator."""
+    import sbtv
+    import sbtv_oracle as o
+    x = synth_image(64, 32, 4)
+    for h in ([[0, 1, -1]], [[0], [1], [-1]], [[1, 2, 3], [4, 5, 6], [7, 8, 9.5]], [[1, -2, 0.5, 3, 1]],
+              np.random.default_rng(1).standard_normal((4, 6))):
+        np.testing.assert_allclose(sbtv.conv2c(x, h), o.conv2c(x, np.asarray(h, dtype=float)), rtol=0, atol=5e-10)
+    np.testing.assert_allclose(sbtv.diffh(x), x - np.roll(x, 1, axis=1), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(sbtv.diffv(x), x - np.roll(x, 1, axis=0), rtol=0, atol=1e-10)
+    xd = sbtv.to_device(x)
+    np.testing.assert_allclose(sbtv.to_host(sbtv.diffh(xd)), x - np.roll(x, 1, axis=1), rtol=0, atol=1e-10)
+    tv = np.sum(np.sqrt(sbtv.diffh(x) ** 2 + sbtv.diffv(x) ** 2))                  # utils/TVnorm.m:2
+    assert sbtv.TVnorm(x) == pytest.approx(tv, rel=1e-12)
+    with pytest.raises(sbtv.SbtvError):
+        sbtv.conv2c(np.zeros((16, 16)), np.ones((17, 1)))
