@@ -131,6 +131,12 @@ int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *
 #define SBTV_PSF_LAPLACE  2
 int sbtv_psf_taps(int kind, int taille, const double *p, double *taps, double *d0, double *d1);
 
+/* The PSF-tracking trace results.err_psf of the SAPG loops (SAPG_algorithm_Guassian.m:146,203-204, _moffat.m:204-205,
+ * _laplace.m:136,190-191):  out[i] = l2(psf(params(i)), psf(p_true)) with utils/l2.m = norm(.)^2 of the MATRIX
+ * (spectral norm, quirk Q9).  ps = [first-parameter trace (n) | second-parameter trace (n)], host arrays; the
+ * Gaussian pairs w1s(i) with w2s(i-1) (quirk Q8), the Moffat's first entry stays 0 as in the reference. */
+int sbtv_err_psf(int kind, int taille, const double *ps, int n, const double *p_true, double phi, double *out);
+
 /* Packed half-spectrum of a real image (debug / test entry for the FFT
  * kernels): out is (M/2) x N complex, column-major, interleaved re/im; row 0
  * holds X[0,l] + i*X[M/2,l].  inverse=1 maps it back (scaled like ifft2). */

@@ -853,7 +853,31 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
     return dict(theta_EB=float(np.mean(thetas[b0:])), p_EB=[float(np.mean(ps[q, b0:])) for q in range(npar)],
                 sigma_EB=float(np.mean(sigmas[b0:])), thetas=thetas, ps=ps, sigmas=sigmas,
                 logPiTraceX=logPiTraceX, logPiTrace_WU=logPiTrace_WU, gXTrace=gX, grads=grads,
-                Xlast_sample=X, prox_last=prox)
+                Xlast_sample=X, prox_last=prox, err_psf=err_psf_trace(kind, ps, p_true, model.psf_size))
+
+
+def err_psf_trace(kind, ps, p_true, psf_size=7):
+    """The PSF-tracking trace `results.err_psf`: l2 (squared SPECTRAL norm, quirk Q9) between the PSF at the current
+    parameters and the true one.  Per family:
+      gaussian  err(1) = l2(psf(w1s(1), w2s(1)), true); err(ii) = l2(psf(w1s(ii), w2s(ii-1)), true)  -- the w2 of the
+                PREVIOUS iteration, quirk Q8 (SAPG_algorithm_Guassian.m:144-146,203-204)
+      moffat    the initial value is stored under another name (`psf_err(1)`, SAPG_algorithm_moffat.m:156), so
+                err_psf(1) stays 0; err(ii) = l2(psf(alphas(ii), betas(ii)), true)   (:204-205)
+      laplace   err(ii) = l2(psf(bs(ii)), true) for every ii   (SAPG_algorithm_laplace.m:134-136,190-191)"""
+    ps = np.atleast_2d(np.asarray(ps, dtype=np.float64))
+    builder = PSF_TAPS[kind][0]
+    true = builder(psf_size, tuple(p_true))
+    n = ps.shape[1]
+    out = np.zeros(n)
+    for i in range(n):
+        if kind == "gaussian":
+            q = (ps[0, i], ps[1, i - 1] if i > 0 else ps[1, 0])
+        else:
+            q = tuple(ps[:, i])
+        if kind == "moffat" and i == 0:
+            continue
+        out[i] = l2(builder(psf_size, q), true)
+    return out
 
 
 def myula(op, im, randn):

@@ -313,6 +313,72 @@ int sbtv_memcpy_d2h(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------
+// results.err_psf of the SAPG loops: l2(psf(params(ii)), psf_true) with utils/l2.m = norm(x-y)^2, where norm() of a
+// MATRIX is the spectral norm (quirk Q9).  Largest eigenvalue of D'D by cyclic Jacobi sweeps (D is at most 15 x 15).
+// ---------------------------------------------------------------------------
+static double spectral_norm_sq(const double *D, int t) {
+    double B[15 * 15];
+    for (int i = 0; i < t; ++i)
+        for (int j = 0; j < t; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < t; ++k) s += D[i * t + k] * D[j * t + k];   // D is column-major: (D'D)(i,j)
+            B[i * t + j] = s;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < t; ++i)
+            for (int j = 0; j < t; ++j) (i == j ? diag : off) += B[i * t + j] * B[i * t + j];
+        if (off <= 1e-34 * diag || off == 0.0) break;
+        for (int p = 0; p < t - 1; ++p)
+            for (int q = p + 1; q < t; ++q) {
+                const double apq = B[p * t + q];
+                if (apq == 0.0) continue;
+                const double theta = (B[q * t + q] - B[p * t + p]) / (2.0 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < t; ++k) {       // rotate columns p, q
+                    const double bkp = B[k * t + p], bkq = B[k * t + q];
+                    B[k * t + p] = cs * bkp - sn * bkq;
+                    B[k * t + q] = sn * bkp + cs * bkq;
+                }
+                for (int k = 0; k < t; ++k) {       // rotate rows p, q
+                    const double bpk = B[p * t + k], bqk = B[q * t + k];
+                    B[p * t + k] = cs * bpk - sn * bqk;
+                    B[q * t + k] = sn * bpk + cs * bqk;
+                }
+            }
+    }
+    double mx = 0.0;
+    for (int i = 0; i < t; ++i) mx = fmax(mx, B[i * t + i]);
+    return mx;
+}
+
+int sbtv_err_psf(int kind, int taille, const double *ps, int n, const double *p_true, double phi, double *out) {
+    if (kind < 0 || kind > 2 || taille < 1 || taille > 15 || !ps || !p_true || !out || n < 1)
+        return fail(nullptr, SBTV_ERR_PSF, "sbtv_err_psf: bad arguments");
+    const int t2 = taille * taille;
+    double truth[225], cur[225], D[225];
+    double pt[3] = {p_true[0], kind == SBTV_PSF_LAPLACE ? 0.0 : p_true[1], kind == SBTV_PSF_GAUSSIAN ? phi : 0.0};
+    int rc = sbtv_psf_taps(kind, taille, pt, truth, nullptr, nullptr);
+    if (rc != 0) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (kind == SBTV_PSF_MOFFAT && i == 0) {          // kept under another name by the reference (:156)
+            out[0] = 0.0;
+            continue;
+        }
+        // gaussian: w1s(ii) with w2s(ii-1) (SAPG_algorithm_Guassian.m:203, quirk Q8); ps = [p0 trace | p1 trace]
+        double p[3] = {ps[i], 0.0, kind == SBTV_PSF_GAUSSIAN ? phi : 0.0};
+        if (kind == SBTV_PSF_GAUSSIAN) p[1] = ps[n + (i > 0 ? i - 1 : 0)];
+        if (kind == SBTV_PSF_MOFFAT) p[1] = ps[n + i];
+        rc = sbtv_psf_taps(kind, taille, p, cur, nullptr, nullptr);
+        if (rc != 0) return rc;
+        for (int q = 0; q < t2; ++q) D[q] = cur[q] - truth[q];
+        out[i] = spectral_norm_sq(D, taille);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // PSF taps (host, double) — formulas of utils/*.m, column-major taille x taille.
 // Element (ii,jj) (0-based) at taps[jj*taille + ii].
 // ---------------------------------------------------------------------------

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sbtv_TVnorm": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "sbtv_A_wrapper": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     "sbtv_psf_taps": (_I, [_I, _I, _P, _P, _P, _P]),
+    "sbtv_err_psf": (_I, [_I, _I, _P, _I, _P, _D, _P]),
     "sbtv_rfft2_packed": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "sbtv_salsa_opts_default": (None, [C.POINTER(sbtv_salsa_opts)]),
     "sbtv_SALSA_v2": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.POINTER(sbtv_salsa_opts), _P, _P, _P, _P, _P, _P,

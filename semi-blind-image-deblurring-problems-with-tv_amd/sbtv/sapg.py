@@ -167,7 +167,27 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
     xs = L.images_result(xl, False)
     for b in range(nch):
         results[b]["Xlast_sample"] = xs[b]
+        results[b]["err_psf"] = _err_psf(kind, o.psf_size, ps[b, :len(names)], [o.p_true[q] for q in range(len(names))],
+                                         o.phi)
     return results
+
+
+def _err_psf(kind, taille, ps, p_true, phi):
+    """results.err_psf: l2 = norm(.)^2 with the MATRIX 2-norm (utils/l2.m, quirk Q9) between the PSF at the traced
+    parameters and the true PSF, evaluated on the host from the parameter traces.  Family quirks as in the
+    reference: Gaussian pairs w1s(ii) with w2s(ii-1) (SAPG_algorithm_Guassian.m:203, Q8); Moffat stores its first
+    value under another name, so err_psf(1) = 0 (SAPG_algorithm_moffat.m:156); Laplace is plain (:136,191)."""
+    lib = L.load_library()
+    tr = np.zeros((2, ps.shape[1]))
+    tr[:ps.shape[0]] = ps                                           # [first-parameter trace | second-parameter trace]
+    pt = np.zeros(2)
+    pt[:len(p_true)] = p_true
+    out = np.zeros(ps.shape[1])
+    rc = lib.sbtv_err_psf(_KIND[kind], int(taille), tr.ctypes.data_as(C.c_void_p), int(ps.shape[1]),
+                          pt.ctypes.data_as(C.c_void_p), float(phi), out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise L.SbtvError(rc, lib.sbtv_last_error(None).decode())
+    return out
 
 
 def _unpack(kind, res, batched):

@@ -100,3 +100,24 @@ def test_plain_c_host_compiles_and_links(tmp_path):
     """The boundary is usable from C without Python or torch: examples/c_host.c builds against include/sbtv.h
     and links libsbtv.so (running it needs the GPU: tests/test_gpu_c_host.py)."""
     assert os.path.exists(_build_c_host(tmp_path))
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "moffat", "laplace"])
+def test_err_psf_host_entry_matches_oracle(kind):
+    """sbtv_err_psf is host arithmetic (PSF builders + a Jacobi spectral norm): it runs without a GPU and must
+    reproduce the oracle's results.err_psf trace incl. the per-family quirks (Q8, Q9, the Moffat first entry)."""
+    import sbtv
+    import sbtv_oracle as o
+    from sbtv.sapg import _err_psf
+    rng = np.random.default_rng(3)
+    n = 40
+    lo, hi = {"gaussian": (0.1, 1.0), "moffat": (0.05, 8.0), "laplace": (0.05, 1.0)}[kind]
+    npar = 1 if kind == "laplace" else 2
+    ps = rng.uniform(lo, hi, (npar, n))
+    ps[:, 5] = ps[:, 4]                                   # repeated parameters
+    p_true = {"gaussian": (0.4, 0.3), "moffat": (0.4, 3.5), "laplace": (0.3,)}[kind]
+    got = _err_psf(kind, 7, ps, p_true, 0.0)
+    ref = o.err_psf_trace(kind, ps, p_true, 7)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-20)
+    if kind == "moffat":
+        assert got[0] == 0.0

@@ -55,6 +55,9 @@ def test_sapg_matches_oracle_with_injected_noise(ctx, kind):
         np.testing.assert_allclose(res[nm + "s"], ref["ps"][q], rtol=1e-8)
         np.testing.assert_allclose(res["grad_" + nm][1:], ref["grads"][1 + q][1:], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(res["logPiTraceX"], ref["logPiTraceX"], rtol=1e-9)
+    np.testing.assert_allclose(res["err_psf"], ref["err_psf"], rtol=1e-6, atol=1e-18)      # results.err_psf (Q8, Q9)
+    if kind == "moffat":
+        assert res["err_psf"][0] == 0.0 and res["err_psf"][1] > 0.0        # first value kept under another name (:156)
     np.testing.assert_allclose(res["logPiTrace_WU"][1:], ref["logPiTrace_WU"][1:], rtol=1e-9)
     np.testing.assert_allclose(res["gXTrace"][:-1], ref["gXTrace"][:-1], rtol=1e-10)
     np.testing.assert_allclose(res["Xlast_sample"], ref["Xlast_sample"], rtol=1e-8, atol=1e-8)
