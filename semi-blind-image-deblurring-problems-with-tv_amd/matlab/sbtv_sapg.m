@@ -52,6 +52,10 @@ end
 results.sigma_EB = eb(4); results.sigmas = psg.Value; results.last_sigma = results.sigmas(end);
 results.grad_theta = gr(:,1)'; results.grad_sigma = gr(:,4)';
 results.c_theta = c.theta; results.c_sigma = c.sigma;
+perr = libpointer('doublePtr', zeros(1,S));                 % results.err_psf (l2 with the matrix 2-norm, utils/l2.m)
+rc = calllib('libsbtv', 'sbtv_err_psf', int32(kind), int32(o.psf_size), [ps(:,1); ps(:,2)], int32(S), p_true, o.phi, perr);
+if rc ~= 0, error('sbtv:SAPG', '%s', calllib('libsbtv', 'sbtv_last_error', [])); end
+results.err_psf = perr.Value;
 results.Xlast_sample = reshape(pxl.Value, M, N);
 results.options = op;
 end
