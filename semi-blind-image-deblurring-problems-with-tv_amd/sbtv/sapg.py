@@ -167,9 +167,30 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
     xs = L.images_result(xl, False)
     for b in range(nch):
         results[b]["Xlast_sample"] = xs[b]
+        # running means from burnIn and their relative change, as the reference logs them while iterating
+        # (SAPG_algorithm_Guassian.m:217-244: mean_* over burnIn..ii for ii > burnIn; tol_*(ii) = relative change
+        # of that mean, NaN while the window is empty)
+        for key, tolkey in [("thetas", "tol_thetas"), ("sigmas", "tol_sigma")] + [(nm + "s", "tol_" + nm + "s") for nm in names]:
+            m, t = _running_mean_and_tol(results[b][key], o.burnIn)
+            results[b]["mean_" + key] = m
+            results[b][tolkey] = t
         results[b]["err_psf"] = _err_psf(kind, o.psf_size, ps[b, :len(names)], [o.p_true[q] for q in range(len(names))],
                                          o.phi)
     return results
+
+
+def _running_mean_and_tol(trace, burnIn):
+    """mean_x(ii - burnIn) = mean(x(burnIn:ii)) for ii > burnIn and tol_x(ii) = |mean(x(burnIn:ii)) - mean(x(burnIn:ii-1))|
+    / mean(x(burnIn:ii-1)) for ii >= 2 (1-based; NaN where a window is empty, like MATLAB's mean of an empty range)."""
+    x = np.asarray(trace, dtype=np.float64)
+    n, b0 = x.size, int(burnIn) - 1                      # 0-based index of burnIn
+    run = np.full(n, np.nan)                             # run[i] = mean(x[b0 .. i]) for i >= b0
+    if b0 < n:
+        run[b0:] = np.cumsum(x[b0:]) / np.arange(1, n - b0 + 1)
+    tol = np.zeros(n)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tol[1:] = np.abs(run[1:] - run[:-1]) / run[:-1]
+    return run[b0 + 1:].copy(), tol
 
 
 def _err_psf(kind, taille, ps, p_true, phi):

@@ -56,6 +56,14 @@ def test_sapg_matches_oracle_with_injected_noise(ctx, kind):
         np.testing.assert_allclose(res["grad_" + nm][1:], ref["grads"][1 + q][1:], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(res["logPiTraceX"], ref["logPiTraceX"], rtol=1e-9)
     np.testing.assert_allclose(res["err_psf"], ref["err_psf"], rtol=1e-6, atol=1e-18)      # results.err_psf (Q8, Q9)
+    # derived logs: mean_thetas(ii-burnIn) = mean(thetas(burnIn:ii)), tol_thetas(ii) (:217-244), written out here
+    th = ref["thetas"]
+    want_mean = [np.mean(th[burnIn - 1:i + 1]) for i in range(burnIn, samples)]
+    np.testing.assert_allclose(res["mean_thetas"], want_mean, rtol=1e-9)
+    i = samples - 1
+    want_tol = abs(np.mean(th[burnIn - 1:i + 1]) - np.mean(th[burnIn - 1:i])) / np.mean(th[burnIn - 1:i])
+    assert res["tol_thetas"][i] == pytest.approx(want_tol, rel=1e-6)
+    assert np.isnan(res["tol_thetas"][burnIn - 1]) and res["tol_thetas"][0] == 0.0
     if kind == "moffat":
         assert res["err_psf"][0] == 0.0 and res["err_psf"][1] > 0.0        # first value kept under another name (:156)
     np.testing.assert_allclose(res["logPiTrace_WU"][1:], ref["logPiTrace_WU"][1:], rtol=1e-9)
