@@ -55,6 +55,7 @@ extern "C" {
 #define SBTV_ERR_PSF            -10   /* bad PSF size / mask does not fit (conv2c.m:15)                               */
 #define SBTV_ERR_NOMEM          -11
 #define SBTV_ERR_NODEVICE       -12   /* no usable GPU: the library has NO CPU fallback                               */
+#define SBTV_ERR_CANARY         -13   /* SBTV_CANARY=1: a kernel wrote outside its workspace (guard band damaged)     */
 
 typedef struct sbtv_ctx sbtv_ctx;
 
@@ -289,6 +290,17 @@ int sbtv_max_eigenval(sbtv_ctx *ctx, const double *taps, int taille, const doubl
  * sbtv_PSNR: utils/PSNR.m:2-4 ; sbtv_MSE: utils/MSE.m:1-4 (dB). out[batch]. */
 int sbtv_PSNR(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags);
 int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags);
+
+/* ---- diagnostics (no counterpart in the reference; SURVEY.md §5 sanitizer / tracing rows) ----
+ * sbtv_diag_canary: with SBTV_CANARY=1 in the environment when the context was created, every device workspace of
+ *   the context carries a 256-byte guard band on both sides and every entry point above ends by verifying all of
+ *   them (SBTV_ERR_CANARY on damage).  This call verifies on demand: *enabled, number of guarded workspaces, damaged
+ *   bytes.  poke = 1 first overwrites the rear guard of one workspace (self-test of the detector) and repairs it.
+ * sbtv_diag_prox_variant: which TV-prox kernel a (M, N, batch) problem takes: out = {columns per wave, waves per
+ *   workgroup, waves per SIMD requested, rows per lane, tiles per image, 1 = temporally fused kernel / 0 = the
+ *   one-iteration kernels (odd M, SBTV_SINGLE_STEP)} — lets a parity test assert which kernel it exercised. */
+int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad);
+int sbtv_diag_prox_variant(sbtv_ctx *ctx, int M, int N, int batch, int out[6]);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,9 @@ def chambolle_prox_TV_stop(g, lam=1.0, maxiter=None, tol=1e-3, tau=0.249,
     ``maxiter`` is REQUIRED (quirk Q1: the default `maxiter = 10` at :80 is
     dead, the loop reads `MaxIter` which only the 'maxiter' option sets, :95-96).
     ``dualvars`` is the M x 2N horizontal concatenation [px py]; the split uses
-    M for the column index (quirk Q2, :105-107).
+    M for the column index (quirk Q2, :105-107).  A (px, py) TUPLE is taken as the two
+    arrays directly: that is what the C-ABI passes (separate pointers, so rectangular
+    images can be warm-started too) and has no counterpart in the reference's option list.
     Returns (f, px, py) like the reference; with return_info also (k, err).
     """
     if maxiter is None:
@@ -111,7 +113,12 @@ def chambolle_prox_TV_stop(g, lam=1.0, maxiter=None, tol=1e-3, tau=0.249,
     g = np.asarray(g, dtype=np.float64)
     px = np.zeros_like(g)
     py = np.zeros_like(g)
-    if dualvars is not None:
+    if isinstance(dualvars, tuple):
+        px = np.array(dualvars[0], dtype=np.float64)
+        py = np.array(dualvars[1], dtype=np.float64)
+        if px.shape != g.shape or py.shape != g.shape:
+            raise ValueError("Wrong size of the dual variables")
+    elif dualvars is not None:
         M, N = g.shape
         Maux, Naux = dualvars.shape
         if M != Maux or Naux != 2 * N:
@@ -854,6 +861,96 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
                 sigma_EB=float(np.mean(sigmas[b0:])), thetas=thetas, ps=ps, sigmas=sigmas,
                 logPiTraceX=logPiTraceX, logPiTrace_WU=logPiTrace_WU, gXTrace=gX, grads=grads,
                 Xlast_sample=X, prox_last=prox, err_psf=err_psf_trace(kind, ps, p_true, model.psf_size))
+
+
+def SAPG_algorithm_shared(setup, chains, samples, warmup, burnIn, randn, chambolleit=25, p_init=None, fix=None,
+                          fix_sigma=False, c=None):
+    """BASELINE.json configs[4] / SURVEY.md §8e row 2: `chains` MYULA chains on ONE image whose gradients are
+    averaged before the (common) parameter update.  This is the reference's multi-sample update
+    `g_*(jj) = ...; G_* = mean(g_*)` (SAPG/SAPG_algorithm_moffat.m:143-173, SAPG_algorithm_laplace.m:146-166,
+    there with `for jj = 1:1`) with the samples drawn by `chains` independent chains instead of one: every chain
+    has its own X, prox and noise, all chains share thetas / PSF parameters / sigmas.  Everything else follows
+    SAPG_algorithm (same line citations).  `randn(shape, chain)` is called once per MYULA step and chain,
+    chains in order 0..chains-1 inside a step, warm-up first.  mean() = sequential sum / n (MATLAB mean)."""
+    kind = setup["kind"]
+    d = DEMO[kind]
+    model = setup["model"]
+    y = setup["y"]
+    dimX = setup["dimX"]
+    lamb = setup["lam"]
+    gam = setup["gamma"]
+    npar = len(d["true"])
+    p_init = tuple(d["init"] if p_init is None else p_init)
+    fixp = tuple(d["fix"] if fix is None else fix)
+    c_theta = d["c_theta"] if c is None else c["theta"]
+    c_p = d["c_p"] if c is None else c["p"]
+    c_sigma = d["c_sigma"] if c is None else c["sigma"]
+    p_true = setup["p_true"]
+    min_sigma = min(setup["sigma_min"], setup["sigma_max"])
+    max_sigma = max(setup["sigma_min"], setup["sigma_max"])
+    sigma_init = setup["sigma"] ** 2 if fix_sigma else setup["sigma_init"]
+    A, AT = model.A, model.AT
+    f = lambda x, p, s2: float(np.linalg.norm(y - A(x, *p), "fro")) ** 2 / (2 * s2)
+    gradF = lambda x, p, s2: np.real(AT(A(x, *p) - y, *p) / s2)
+    grad_p = lambda i, x, p, s2: float(np.real(np.sum(model.dA(i, x, *p) * (A(x, *p) - y)) / s2))
+    gradF_sigma = lambda x, p, s2: float(np.linalg.norm(y - A(x, *p), "fro")) ** 2 / (2 * s2 ** 2) - dimX / (2 * s2)
+    proxG = lambda x, theta: chambolle_prox_TV_stop(x, lam=lamb * theta, maxiter=chambolleit)[0]
+    logPi = lambda x, theta, p, s2: -f(x, p, s2) - theta * TVnorm(x)
+    delta = lambda i: setup["d_scale"] * ((i ** (-setup["d_exp"])) / dimX)
+    mean = lambda v: sum(v[1:], v[0]) / len(v)
+
+    C = int(chains)
+    Xs = [y.copy() for _ in range(C)]
+    proxs = [None] * C
+    if warmup > 0:
+        for k in range(C):
+            proxs[k] = proxG(Xs[k], setup["th_init"])
+        for ii in range(2, warmup + 1):
+            for k in range(C):
+                Xs[k] = np.abs(Xs[k] + gam * (proxs[k] - Xs[k]) / lamb - gam * gradF(Xs[k], p_init, sigma_init)
+                               + math.sqrt(2 * gam) * randn(y.shape, k))
+                proxs[k] = proxG(Xs[k], setup["th_init"])
+    thetas = np.zeros(samples); thetas[0] = setup["th_init"]
+    sigmas = np.zeros(samples); sigmas[0] = sigma_init
+    ps = np.zeros((npar, samples)); ps[:, 0] = p_init
+    logPiTraceX = np.zeros((C, samples))
+    gX = np.zeros((C, samples))
+    grads = np.zeros((npar + 2, samples))
+    for k in range(C):
+        logPiTraceX[k, 0] = logPi(Xs[k], thetas[0], tuple(ps[:, 0]), sigmas[0])
+        proxs[k] = proxG(Xs[k], thetas[0])
+    for ii in range(2, samples + 1):
+        i0 = ii - 1
+        pm = tuple(ps[:, i0 - 1])
+        g_t, g_s = [0.0] * C, [0.0] * C
+        g_p = [[0.0] * C for _ in range(npar)]
+        for k in range(C):                                   # the `for jj` loop, one sample per chain
+            Z = randn(y.shape, k)
+            Xs[k] = np.abs(Xs[k] + gam * (proxs[k] - Xs[k]) / lamb - gam * gradF(Xs[k], pm, sigmas[i0 - 1])
+                           + math.sqrt(2 * gam) * Z)
+            proxs[k] = proxG(Xs[k], thetas[i0 - 1])
+            for q in range(npar):
+                g_p[q][k] = grad_p(q, Xs[k], pm, sigmas[i0 - 1])
+            g_s[k] = gradF_sigma(Xs[k], pm, sigmas[i0 - 1])
+            g_t[k] = dimX / thetas[i0 - 1] - TVnorm(Xs[k])
+        G_t, G_s = mean(g_t), mean(g_s)
+        thetas[i0] = min(max(thetas[i0 - 1] + c_theta * delta(ii) * G_t, setup["min_th"]), setup["max_th"])
+        for q in range(npar):
+            G = mean(g_p[q])
+            grads[1 + q, i0] = G
+            pq = p_true[q] if fixp[q] else ps[q, i0 - 1] - c_p[q] * delta(ii) * G
+            ps[q, i0] = min(max(pq, d["pmin"][q]), d["pmax"][q])
+        s_new = sigma_init if fix_sigma else sigmas[i0 - 1] + c_sigma * delta(ii) * G_s
+        sigmas[i0] = min(max(s_new, min_sigma), max_sigma)
+        grads[0, i0] = G_t
+        grads[npar + 1, i0] = G_s
+        for k in range(C):
+            logPiTraceX[k, i0] = logPi(Xs[k], thetas[i0 - 1], pm, sigmas[i0 - 1])
+            gX[k, i0 - 1] = TVnorm(Xs[k])
+    b0 = int(burnIn) - 1
+    return dict(theta_EB=float(np.mean(thetas[b0:])), p_EB=[float(np.mean(ps[q, b0:])) for q in range(npar)],
+                sigma_EB=float(np.mean(sigmas[b0:])), thetas=thetas, ps=ps, sigmas=sigmas,
+                logPiTraceX=logPiTraceX, gXTrace=gX, grads=grads, Xlast_samples=Xs)
 
 
 def err_psf_trace(kind, ps, p_true, psf_size=7):

@@ -635,7 +635,7 @@ int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, cons
     }
     SBTV_TRY(stage_out_copy(ctx, x_out, xo, cnt, flags));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const double *taps, int taille,
@@ -671,7 +671,7 @@ int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     }
     SBTV_TRY(stage_out_copy(ctx, x_out, xo, cnt, flags));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 }  // extern "C"

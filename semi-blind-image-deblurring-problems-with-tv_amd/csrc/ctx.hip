@@ -28,18 +28,103 @@ int fail_hip(sbtv_ctx *ctx, hipError_t e, const char *what, const char *file, in
     return (int)e > 0 ? (int)e : 999;
 }
 
+// ---- workspace guard bands (sanitizer row) -------------------------------------------
+// GPU AddressSanitizer is not available on the target pool, so an out-of-bounds store of a kernel is caught
+// the poor man's way: with SBTV_CANARY=1 every named workspace is allocated with kGuard pattern bytes in
+// front of and behind it, and every C-ABI call ends with one small kernel that checks all of them.
+constexpr size_t kGuard = 256;
+constexpr unsigned char kGuardByte = 0xA5;
+struct CanaryDesc { const unsigned char *lo, *hi; };
+
+__global__ __launch_bounds__(256) void canary_check_kernel(const CanaryDesc *__restrict__ d, int *__restrict__ bad) {
+    const CanaryDesc c = d[blockIdx.x];
+    const int t = threadIdx.x;      // kGuard == blockDim.x
+    const int n = (c.lo[t] != kGuardByte ? 1 : 0) + (c.hi[t] != kGuardByte ? 1 : 0);
+    if (n) atomicAdd(&bad[blockIdx.x], n);
+}
+
+int canary_verify(sbtv_ctx *ctx, int *nbuf, int *nbad, std::string *first_bad) {
+    *nbuf = 0;
+    *nbad = 0;
+    if (!ctx->canary) return 0;
+    std::vector<CanaryDesc> h;
+    std::vector<const std::string *> names;
+    for (auto &kv : ctx->ws)
+        if (kv.second.base) {
+            const unsigned char *b = static_cast<const unsigned char *>(kv.second.base);
+            h.push_back({b, b + kGuard + kv.second.bytes});
+            names.push_back(&kv.first);
+        }
+    const int n = (int)h.size();
+    *nbuf = n;
+    if (n == 0) return 0;
+    if (n > ctx->canary_cap) {
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->canary_desc) SBTV_HIP(ctx, hipFree(ctx->canary_desc));
+        if (ctx->canary_bad) SBTV_HIP(ctx, hipFree(ctx->canary_bad));
+        ctx->canary_cap = n + 32;
+        SBTV_HIP(ctx, hipMalloc(&ctx->canary_desc, sizeof(CanaryDesc) * ctx->canary_cap));
+        SBTV_HIP(ctx, hipMalloc((void **)&ctx->canary_bad, sizeof(int) * ctx->canary_cap));
+        ctx->canary_dirty = true;
+    }
+    if (ctx->canary_dirty || n != ctx->canary_n) {
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SBTV_HIP(ctx, hipMemcpy(ctx->canary_desc, h.data(), sizeof(CanaryDesc) * n, hipMemcpyHostToDevice));
+        ctx->canary_n = n;
+        ctx->canary_dirty = false;
+    }
+    SBTV_HIP(ctx, hipMemsetAsync(ctx->canary_bad, 0, sizeof(int) * n, ctx->stream));
+    hipLaunchKernelGGL(canary_check_kernel, dim3(n), dim3((unsigned)kGuard), 0, ctx->stream,
+                       static_cast<const CanaryDesc *>(ctx->canary_desc), ctx->canary_bad);
+    SBTV_HIP(ctx, hipGetLastError());
+    std::vector<int> bad(n);
+    SBTV_HIP(ctx, hipMemcpyAsync(bad.data(), ctx->canary_bad, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < n; ++q)
+        if (bad[q]) {
+            if (*nbad == 0 && first_bad) *first_bad = *names[q];
+            *nbad += bad[q];
+        }
+    return 0;
+}
+
+int canary_epilogue(sbtv_ctx *ctx, int rc) {
+    if (!ctx || !ctx->canary || rc != 0) return rc;
+    int nbuf = 0, nbad = 0;
+    std::string name;
+    SBTV_TRY(canary_verify(ctx, &nbuf, &nbad, &name));
+    if (nbad)
+        return fail(ctx, SBTV_ERR_CANARY, "guard band of workspace '" + name + "' was overwritten (" +
+                                              std::to_string(nbad) + " bytes in all workspaces)");
+    return 0;
+}
+
 int ws_get(sbtv_ctx *ctx, const char *name, size_t bytes, void **out) {
     DevBuf &b = ctx->ws[name];
-    if (b.bytes < bytes) {
-        if (b.p) {
+    if (b.bytes < bytes || !b.base) {
+        if (b.base) {
             SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            SBTV_HIP(ctx, hipFree(b.p));
-            b.p = nullptr;
+            if (ctx->canary) {                      // the evidence would be freed with the buffer
+                int nbuf = 0, nbad = 0;
+                std::string bad;
+                SBTV_TRY(canary_verify(ctx, &nbuf, &nbad, &bad));
+                if (nbad) return fail(ctx, SBTV_ERR_CANARY, "guard band of workspace '" + bad + "' was overwritten");
+            }
+            SBTV_HIP(ctx, hipFree(b.base));
+            b.p = b.base = nullptr;
             b.bytes = 0;
         }
-        size_t want = (bytes + 255) & ~size_t(255);
-        SBTV_HIP(ctx, hipMalloc(&b.p, want));
+        // canary mode sizes the buffer tightly (16-byte granule) so that the rear guard starts right behind it
+        const size_t want = ctx->canary ? ((bytes + 15) & ~size_t(15)) : ((bytes + 255) & ~size_t(255));
+        const size_t guard = ctx->canary ? kGuard : 0;
+        SBTV_HIP(ctx, hipMalloc(&b.base, want + 2 * guard));
+        b.p = static_cast<unsigned char *>(b.base) + guard;
         b.bytes = want;
+        if (ctx->canary) {
+            SBTV_HIP(ctx, hipMemsetAsync(b.base, kGuardByte, kGuard, ctx->stream));
+            SBTV_HIP(ctx, hipMemsetAsync(static_cast<unsigned char *>(b.p) + want, kGuardByte, kGuard, ctx->stream));
+            ctx->canary_dirty = true;
+        }
     }
     *out = b.p;
     return 0;
@@ -220,9 +305,19 @@ int sbtv_ctx_create(int device, sbtv_ctx **out) {
     sbtv_ctx *ctx = new sbtv_ctx();
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
-    SBTV_HIP(ctx, hipSetDevice(device));
-    SBTV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    for (auto &ev : ctx->ev) SBTV_HIP(ctx, hipEventCreate(&ev));
+    if (const char *cn = getenv("SBTV_CANARY")) ctx->canary = (cn[0] != '\0' && cn[0] != '0');
+    auto init = [&]() -> int {
+        SBTV_HIP(ctx, hipSetDevice(device));
+        SBTV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (auto &ev : ctx->ev) SBTV_HIP(ctx, hipEventCreate(&ev));
+        return 0;
+    };
+    const int rc = init();
+    if (rc != 0) {
+        const std::string msg = ctx->err;       // the message outlives the half-built context
+        (void)sbtv_ctx_destroy(ctx);
+        return fail(nullptr, rc, msg);
+    }
     *out = ctx;
     return 0;
 }
@@ -231,9 +326,11 @@ int sbtv_ctx_destroy(sbtv_ctx *ctx) {
     if (!ctx) return 0;
     // teardown: release everything even if one call fails (nothing useful can be done about it here)
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->ws)
-        if (kv.second.p) (void)hipFree(kv.second.p);
+        if (kv.second.base) (void)hipFree(kv.second.base);
+    if (ctx->canary_desc) (void)hipFree(ctx->canary_desc);
+    if (ctx->canary_bad) (void)hipFree(ctx->canary_bad);
     for (auto &kv : ctx->twiddles) (void)hipFree(kv.second);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &ev : ctx->ev)
@@ -281,6 +378,35 @@ int sbtv_callcounter_reset(sbtv_ctx *ctx) {
 int sbtv_last_timing(const sbtv_ctx *ctx, double out[4]) {
     if (!ctx || !out) return SBTV_ERR_BADARG;
     for (int i = 0; i < 4; ++i) out[i] = ctx->timing[i];
+    return 0;
+}
+
+int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad) {
+    if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    if (enabled) *enabled = ctx->canary ? 1 : 0;
+    int nb = 0, bad = 0;
+    if (ctx->canary && poke) {
+        // simulate a kernel writing one element past the end of the first workspace
+        for (auto &kv : ctx->ws)
+            if (kv.second.base) {
+                SBTV_HIP(ctx, hipMemsetAsync(static_cast<unsigned char *>(kv.second.p) + kv.second.bytes, 0, 8, ctx->stream));
+                break;
+            }
+    }
+    std::string name;
+    SBTV_TRY(canary_verify(ctx, &nb, &bad, &name));
+    if (ctx->canary && poke && bad) {
+        // repair the poked guard so that the context stays usable
+        for (auto &kv : ctx->ws)
+            if (kv.second.base) {
+                SBTV_HIP(ctx, hipMemsetAsync(static_cast<unsigned char *>(kv.second.p) + kv.second.bytes, kGuardByte, kGuard, ctx->stream));
+                break;
+            }
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (nbuf) *nbuf = nb;
+    if (nbad) *nbad = bad;
     return 0;
 }
 

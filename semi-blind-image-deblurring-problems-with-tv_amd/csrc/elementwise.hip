@@ -300,7 +300,7 @@ static int metric_common(sbtv_ctx *ctx, const double *x_true, const double *x, i
         else
             out[b] = 10 * log10(se / (double)P);                          // utils/MSE.m:3
     }
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 int sbtv_PSNR(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags) {

@@ -890,7 +890,7 @@ int sbtv_rfft2_packed(sbtv_ctx *ctx, const double *in, double *out, int M, int N
     }
     SBTV_TRY(stage_out_copy(ctx, out, outd, cnt, flags));
     if (!(flags & SBTV_DEVICE_PTRS)) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *mu, const double *x, double *out,
@@ -939,7 +939,7 @@ int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *
     ctx->calls += batch;
     SBTV_TRY(stage_out_copy(ctx, out, outd, cnt, flags));
     if (!(flags & SBTV_DEVICE_PTRS)) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 }  // extern "C"

@@ -257,21 +257,26 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     int active = batch;
     double ms_prox = 0.0;
     long long prox_iters_run = 0;
-    hipEvent_t ev_done[2], ev_p0[2], ev_p1[2];
+    // events and captured graphs of this call: released on EVERY return path
+    struct LoopResources {
+        hipEvent_t done[2] = {nullptr, nullptr}, p0[2] = {nullptr, nullptr}, p1[2] = {nullptr, nullptr};
+        hipGraphExec_t gexec[2] = {nullptr, nullptr};
+        ~LoopResources() {
+            for (int s = 0; s < 2; ++s) {
+                if (gexec[s]) (void)hipGraphExecDestroy(gexec[s]);
+                if (done[s]) (void)hipEventDestroy(done[s]);
+                if (p0[s]) (void)hipEventDestroy(p0[s]);
+                if (p1[s]) (void)hipEventDestroy(p1[s]);
+            }
+        }
+    } res;
+    hipEvent_t(&ev_done)[2] = res.done, (&ev_p0)[2] = res.p0, (&ev_p1)[2] = res.p1;
+    hipGraphExec_t(&gexec)[2] = res.gexec;
     for (int s = 0; s < 2; ++s) {
         SBTV_HIP(ctx, hipEventCreate(&ev_done[s]));
         SBTV_HIP(ctx, hipEventCreate(&ev_p0[s]));
         SBTV_HIP(ctx, hipEventCreate(&ev_p1[s]));
     }
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    auto destroy_events = [&]() {
-        for (int s = 0; s < 2; ++s) {
-            if (gexec[s]) (void)hipGraphExecDestroy(gexec[s]);
-            (void)hipEventDestroy(ev_done[s]);
-            (void)hipEventDestroy(ev_p0[s]);
-            (void)hipEventDestroy(ev_p1[s]);
-        }
-    };
     const auto t0 = std::chrono::steady_clock::now();
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
 
@@ -397,7 +402,6 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     }
     if (rc != 0) {
         (void)hipStreamSynchronize(ctx->stream);
-        destroy_events();
         return rc;
     }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -410,7 +414,6 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         ctx->timing[2] = (double)prox_iters_run / batch;      // Chambolle iterations (image-averaged)
         ctx->timing[3] = 40.0 * (double)P * (double)prox_iters_run;
     }
-    destroy_events();
     if (x_out) {
         // image b's result is the x written by ITS last processed iteration
         for (int b = 0; b < batch; ++b) {
@@ -426,7 +429,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         if (numAt) numAt[b] = h_numAt[b];
         if (n_outer) n_outer[b] = h_nouter[b];
     }
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 }  // extern "C"

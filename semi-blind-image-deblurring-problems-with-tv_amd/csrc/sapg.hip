@@ -144,7 +144,7 @@ int sbtv_max_eigenval(sbtv_ctx *ctx, const double *taps, int taille, const doubl
     }
     *val_out = val;
     if (iters) *iters = (k > max_iter) ? max_iter : k;
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -339,7 +339,7 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_iter)
         for (int b = 0; b < batch; ++b) n_iter[b] = h_niter[b];
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -420,7 +420,7 @@ int sbtv_myula(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const do
     }
     SBTV_TRY(stage_out_copy(ctx, x_out, X, cnt, flags));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -834,7 +834,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     }
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)nsteps_noise;
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 }  // extern "C"

@@ -41,8 +41,9 @@ struct SalsaScal {
 };
 
 struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
+    void *p = nullptr;       // what the kernels see
+    void *base = nullptr;    // what hipMalloc returned (p - guard band in canary mode, else p)
+    size_t bytes = 0;        // capacity behind p
 };
 
 }  // namespace sbtv
@@ -60,6 +61,13 @@ struct sbtv_ctx {
     size_t pinned_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int cu_count = 256;
+    // SBTV_CANARY=1 (read when the context is created): every workspace gets a guard band on both sides,
+    // verified at the end of each C-ABI call (canary_epilogue)
+    bool canary = false;
+    bool canary_dirty = true;                  // the descriptor table below is stale
+    void *canary_desc = nullptr;               // device: {lo guard, hi guard} per workspace
+    int *canary_bad = nullptr;                 // device: bad bytes per workspace
+    int canary_n = 0, canary_cap = 0;
 };
 
 namespace sbtv {
@@ -90,6 +98,9 @@ inline int ws_get_t(sbtv_ctx *ctx, const char *name, size_t count, T **out) {
     return rc;
 }
 int pinned_get(sbtv_ctx *ctx, size_t bytes, void **out);
+// end of a C-ABI call: with SBTV_CANARY=1 verify every guard band (one tiny kernel + a sync), else return rc
+int canary_epilogue(sbtv_ctx *ctx, int rc);
+int canary_verify(sbtv_ctx *ctx, int *nbuf, int *nbad, std::string *first_bad);
 int twiddle_get(sbtv_ctx *ctx, int n, const double2 **out);
 
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }

@@ -643,7 +643,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         // switches it off).
         static const char *env_inl = getenv("SBTV_INLINE_CTRL");
         const bool env_inline = env_inl ? (env_inl[0] != '0') : ((size_t)pl.fnblk * pl.batch <= 512);
-        auto launch_fused = [&](int steps, int redo, int write_f) {
+        auto launch_fused = [&](int steps, int redo, int write_f) -> int {
             bool launched = false;
             const int inl = (!redo && env_inline) ? 1 : 0;
             const int kflags = inl | (cold ? 2 : 0);            // bit 0: in-kernel stop rule, bit 1: cold start
@@ -694,15 +694,18 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED1_CASE(6, 8, 6)
             SBTV_FUSED1_CASE(6, 8, 4)
 #undef SBTV_FUSED1_CASE
-            (void)launched;
+            // a plan whose geometry matches no compiled variant must not pass silently (nothing was enqueued)
+            if (!launched)
+                return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: no fused Chambolle kernel is compiled for this tile geometry");
             // the re-run launch books its own result (last-workgroup ticket; nothing at all when it is empty)
             if (!inl && !redo)
                 hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FH), 0, ctx->stream,
                                    pl.ctrl, pl.partials, pl.fnblk, steps, redo, write_f);
+            return 0;
         };
         const int wf = f_out ? 1 : 0;
-        for (int l = 0; l < nl; ++l) launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0);
-        launch_fused(0, 1, wf);     // redo pass; doubles as the finish-only pass when f is not valid yet
+        for (int l = 0; l < nl; ++l) SBTV_TRY(launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0));
+        SBTV_TRY(launch_fused(0, 1, wf));     // redo pass; doubles as the finish-only pass when f is not valid yet
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
@@ -817,6 +820,21 @@ int sbtv_chambolle_prox_TV_stop(sbtv_ctx *ctx, const double *g, int M, int N, in
             if (err_out) err_out[b] = hc[b].err;
         }
     }
+    return canary_epilogue(ctx, 0);
+}
+
+int sbtv_diag_prox_variant(sbtv_ctx *ctx, int M, int N, int batch, int out[6]) {
+    if (!ctx || !out || M < 2 || N < 2 || batch < 1) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    ProxPlan pl;
+    SBTV_TRY(prox_plan(ctx, M, N, batch, &pl));
+    static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
+    out[0] = pl.cj;
+    out[1] = pl.nw;
+    out[2] = pl.minw;
+    out[3] = pl.rpl;
+    out[4] = pl.fnblk;
+    out[5] = (M % 2 == 0 && !env_single && !g_force_single_step) ? 1 : 0;
     return 0;
 }
 
@@ -831,7 +849,7 @@ int sbtv_TVnorm(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double 
     SBTV_TRY(tvnorm_dev(ctx, xd, M, N, batch, od));
     SBTV_HIP(ctx, hipMemcpyAsync(out, od, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return canary_epilogue(ctx, 0);
 }
 
 }  // extern "C"

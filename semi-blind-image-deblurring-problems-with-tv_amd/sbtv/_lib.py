@@ -22,6 +22,7 @@ ERRORS = {
     -1: "SBTV_ERR_BADARG", -2: "SBTV_ERR_SIZE", -3: "SBTV_ERR_MAXITER", -4: "SBTV_ERR_DUALVARS",
     -5: "SBTV_ERR_MODE", -6: "SBTV_ERR_STOPCRITERION", -7: "SBTV_ERR_INIT", -8: "SBTV_ERR_MISSING_AT",
     -9: "SBTV_ERR_MISSING_LS", -10: "SBTV_ERR_PSF", -11: "SBTV_ERR_NOMEM", -12: "SBTV_ERR_NODEVICE",
+    -13: "SBTV_ERR_CANARY",
 }
 
 
@@ -94,6 +95,8 @@ SIGNATURES = {
     "sbtv_max_eigenval": (_I, [_P, _P, _I, _P, _I, _I, _D, _I, _P, _P, _I]),
     "sbtv_PSNR": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
     "sbtv_MSE": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
+    "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
 }
 
 _lib = None
@@ -171,6 +174,20 @@ class Context:
 
     def reset_calls(self):
         self.check(self.lib.sbtv_callcounter_reset(self.h))
+
+    def canary(self, poke=False):
+        """Guard-band check of every device workspace (active when SBTV_CANARY=1 was set before the context was
+        created): dict(enabled, buffers, bad_bytes).  poke=True damages one guard first (self-test) and repairs it."""
+        en, nb, bad = _I(0), _I(0), _I(0)
+        self.check(self.lib.sbtv_diag_canary(self.h, int(bool(poke)), C.byref(en), C.byref(nb), C.byref(bad)))
+        return dict(enabled=bool(en.value), buffers=nb.value, bad_bytes=bad.value)
+
+    def prox_variant(self, M, N, batch=1):
+        """Which TV-prox kernel an M x N x batch problem takes (sbtv_diag_prox_variant)."""
+        out = (_I * 6)()
+        self.check(self.lib.sbtv_diag_prox_variant(self.h, int(M), int(N), int(batch), out))
+        return dict(cols_per_wave=out[0], waves=out[1], waves_per_simd=out[2], rows_per_lane=out[3], tiles=out[4],
+                    fused=bool(out[5]))
 
     def last_timing(self):
         out = (C.c_double * 4)()

@@ -391,3 +391,105 @@ def test_plain_myula_chain_matches_oracle(ctx):
     two = sbtv.myula(dict(op, seed=5, y=np.stack([st["y"], st["y"]])), x)
     np.testing.assert_array_equal(two[0], a)
     np.testing.assert_array_equal(two[1], sbtv.myula(dict(op, seed=5, chain_offset=1), x))
+
+
+def _sapg_vs_oracle(kind, x, samples, warmup, burnIn, p_init=None, fix=None, seed=11, grad_rtol=1e-6):
+    """One injected-noise SAPG run through the C-ABI against the oracle (traces, gradients, logPi, last sample)."""
+    import sbtv
+    import sbtv_oracle as o
+    M, N = x.shape
+    rng = np.random.default_rng(seed)
+    st = o.demo_setup(kind, x, rng.standard_normal((M, N)), evMax=0.99)
+    nz = rng.standard_normal((max(warmup - 1, 0) + samples - 1, M, N))
+    it = iter(nz)
+    ref = o.SAPG_algorithm(st, samples=samples, warmup=warmup, burnIn=burnIn, randn=lambda s: next(it), chambolleit=25,
+                           p_init=p_init, fix=fix)
+    op, c, names = _op_struct(kind, st, samples, warmup, burnIn)
+    for q, nm in enumerate(names):
+        if p_init is not None:
+            op[nm + "_init"] = p_init[q]
+        if fix is not None:
+            op["fix_" + nm] = int(fix[q])
+    fn = {"gaussian": sbtv.SAPG_algorithm_Guassian, "moffat": sbtv.SAPG_algorithm_moffat,
+          "laplace": sbtv.SAPG_algorithm_laplace}[kind]
+    res = fn(st["y"], op, c, noise=nz)[-1]
+    np.testing.assert_allclose(res["thetas"], ref["thetas"], rtol=1e-9)
+    np.testing.assert_allclose(res["sigmas"], ref["sigmas"], rtol=1e-9)
+    for q, nm in enumerate(names):
+        np.testing.assert_allclose(res[nm + "s"], ref["ps"][q], rtol=1e-8)
+        assert ref["ps"][q][-1] != ref["ps"][q][0], "the PSF parameter must move in this test"
+        # gradients <dA_q X, AX - y>/sigma^2: a sum over the spectrum with cancellation, so a relative bar on
+        # the scale of the terms (Parseval form vs the reference's spatial sum)
+        np.testing.assert_allclose(res["grad_" + nm][1:], ref["grads"][1 + q][1:], rtol=grad_rtol,
+                                   atol=grad_rtol * np.max(np.abs(ref["grads"][1 + q])))
+    np.testing.assert_allclose(res["grad_theta"][1:], ref["grads"][0][1:], rtol=1e-9)
+    np.testing.assert_allclose(res["grad_sigma"][1:], ref["grads"][len(names) + 1][1:], rtol=1e-8)
+    np.testing.assert_allclose(res["logPiTraceX"], ref["logPiTraceX"], rtol=1e-9)
+    if warmup > 1:
+        np.testing.assert_allclose(res["logPiTrace_WU"][1:], ref["logPiTrace_WU"][1:], rtol=1e-9)
+    np.testing.assert_allclose(res["gXTrace"][:-1], ref["gXTrace"][:-1], rtol=1e-10)
+    np.testing.assert_allclose(res["Xlast_sample"], ref["Xlast_sample"], rtol=1e-8, atol=1e-8)
+
+
+def test_sapg_gaussian_512_free_w1_w2_matches_oracle(ctx, man512):
+    """The demo size (run_Gaussian_demo.m:47-50 runs on 512 x 512) with BOTH Gaussian widths estimated
+    (fix_w1 = fix_w2 = 0, init 0.5 / 0.3 as run_Gaussian_demo.m:68-69): exercises the fused gradient pass
+    `fft_rows_kernel<9, RK, OP_GRAD>` with the D1 / D2 derivative spectra incl. its packed row 0, and the tap-spectrum
+    kernel on a moving PSF, against the oracle's 24-FFT formulation (SAPG_algorithm_Guassian.m:158-208)."""
+    _sapg_vs_oracle("gaussian", man512, samples=4, warmup=3, burnIn=2, p_init=(0.5, 0.3), fix=(False, False))
+
+
+def test_sapg_laplace_1024_matches_oracle(ctx, man512):
+    """configs[3] size (1024 x 1024, Laplace PSF, b estimated): the N >= 1024 branch of the gradient row pass and
+    `psf_spectrum_kernel` with lch > 1 against the oracle (SAPG_algorithm_laplace.m:144-224)."""
+    x = np.tile(man512, (2, 2))
+    _sapg_vs_oracle("laplace", x, samples=3, warmup=2, burnIn=2)
+
+
+def test_sapg_moffat_1024x512_matches_oracle(ctx, man512):
+    """Rectangular image (M = 1024 rows, N = 512 columns), Moffat PSF with alpha and beta estimated."""
+    x = np.tile(man512, (2, 1))
+    _sapg_vs_oracle("moffat", x, samples=3, warmup=2, burnIn=2)
+
+
+def test_sapg_shared_gradient_chains_match_oracle(ctx):
+    """configs[4] data path against its oracle restatement (`SAPG_algorithm_shared`: the reference's
+    `G = mean(g_*)` update, SAPG_algorithm_moffat.m:158-173, with one sample per chain): two chains on one image,
+    injected noise per chain, PSF parameters free."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    x = synth_image(M, N, 3)
+    rng = np.random.default_rng(2)
+    for kind, p_init in (("gaussian", (0.5, 0.35)), ("moffat", None)):
+        st = o.demo_setup(kind, x, rng.standard_normal((M, N)), evMax=0.99)
+        C_, samples, warmup, burnIn = 2, 7, 4, 4
+        nz = rng.standard_normal((warmup - 1 + samples - 1, C_, M, N))      # [step][chain]
+        step = [0] * C_
+
+        def randn(shape, k):
+            z = nz[step[k], k]
+            step[k] += 1
+            return z
+        fix = (False, False)
+        ref = o.SAPG_algorithm_shared(st, C_, samples, warmup, burnIn, randn, p_init=p_init, fix=fix)
+        op, c, names = _op_struct(kind, st, samples, warmup, burnIn)
+        for q, nm in enumerate(names):
+            op["fix_" + nm] = 0
+            if p_init is not None:
+                op[nm + "_init"] = p_init[q]
+        op["chains"] = C_
+        fn = sbtv.SAPG_algorithm_Guassian if kind == "gaussian" else sbtv.SAPG_algorithm_moffat
+        res = fn(st["y"], op, c, noise=nz, share_gradients=True)[-1]
+        assert len(res) == C_
+        for k in range(C_):
+            np.testing.assert_allclose(res[k]["thetas"], ref["thetas"], rtol=1e-9)
+            np.testing.assert_allclose(res[k]["sigmas"], ref["sigmas"], rtol=1e-9)
+            for q, nm in enumerate(names):
+                np.testing.assert_allclose(res[k][nm + "s"], ref["ps"][q], rtol=1e-8)
+                assert ref["ps"][q][-1] != ref["ps"][q][0]
+            np.testing.assert_allclose(res[k]["grad_theta"][1:], ref["grads"][0][1:], rtol=1e-9)
+            np.testing.assert_allclose(res[k]["logPiTraceX"], ref["logPiTraceX"][k], rtol=1e-9)
+            np.testing.assert_allclose(res[k]["gXTrace"][:-1], ref["gXTrace"][k][:-1], rtol=1e-10)
+            np.testing.assert_allclose(res[k]["Xlast_sample"], ref["Xlast_samples"][k], rtol=1e-8, atol=1e-8)
+        assert np.max(np.abs(res[0]["Xlast_sample"] - res[1]["Xlast_sample"])) > 1e-3
