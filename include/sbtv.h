@@ -55,6 +55,7 @@ extern "C" {
 #define SBTV_ERR_PSF            -10   /* bad PSF size / mask does not fit (conv2c.m:15)                               */
 #define SBTV_ERR_NOMEM          -11
 #define SBTV_ERR_NODEVICE       -12   /* no usable GPU: the library has NO CPU fallback                               */
+#define SBTV_ERR_PEER           -14   /* shared-gradient chains: another rank reported an error through reduce_fn     */
 #define SBTV_ERR_CANARY         -13   /* SBTV_CANARY=1: a kernel wrote outside its workspace (guard band damaged)     */
 
 typedef struct sbtv_ctx sbtv_ctx;
@@ -259,8 +260,12 @@ typedef struct sbtv_sapg_opts {
  *          logpi [batch*samples]; logpi_wu [batch*warmup]; gx [batch*samples]; grads [batch*4*samples]
  *   eb[batch*4] : theta_EB, p0_EB, p1_EB, sigma2_EB ;  x_last: last sample (may be NULL)
  *   reduce_fn: when share_gradients=1 and the chains are spread over several
- *          processes, called once per iteration with (user, buf, n) to SUM buf[n]
- *          across processes in place (e.g. an RCCL all-reduce); may be NULL. */
+ *          processes, called once per iteration with (user, buf, n = 6) to SUM buf[n]
+ *          across processes in place (e.g. an RCCL all-reduce); may be NULL.
+ *          buf = {sum G_theta, sum G_p0, sum G_p1, sum G_sigma, chains, failed ranks}: a rank whose iteration
+ *          failed locally still calls reduce_fn (with failed = 1) before it returns its error, and every other
+ *          rank then returns SBTV_ERR_PEER, so no rank is left waiting inside the collective.  Every rank must
+ *          run at least one chain (batch >= 1). */
 typedef int (*sbtv_allreduce_fn)(void *user, double *buf, int n);
 int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                         const sbtv_sapg_opts *op, const double *x0, const double *noise,
@@ -298,8 +303,15 @@ int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N,
  *   bytes.  poke = 1 first overwrites the rear guard of one workspace (self-test of the detector) and repairs it.
  * sbtv_diag_prox_variant: which TV-prox kernel a (M, N, batch) problem takes: out = {columns per wave, waves per
  *   workgroup, waves per SIMD requested, rows per lane, tiles per image, 1 = temporally fused kernel / 0 = the
- *   one-iteration kernels (odd M, SBTV_SINGLE_STEP)} — lets a parity test assert which kernel it exercised. */
+ *   one-iteration kernels (odd M, SBTV_SINGLE_STEP)} — lets a parity test assert which kernel it exercised.
+ * sbtv_diag_time_pass: times ONE pass of the hot path on scratch data of the given shape with HIP events on the
+ *   context stream (`reps` launches after two untimed ones) -> average ms per launch and the algorithmic bytes of one
+ *   launch.  pass: 0 forward column FFT of u+bu; 1 row pass with the SALSA spectral solve (forward FFT, operator,
+ *   inverse FFT); 2 inverse column FFT fused with the SALSA bookkeeping; 3 plain inverse column FFT; 4 forward row
+ *   FFT; 5 / 6 row pass with the SAPG gradient operators (with / without the PSF-parameter sums); 7 warm-started TV
+ *   prox of 10 iterations incl. f (one SALSA outer iteration's share); 8 cold TV prox of 25 iterations incl. f. */
 int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad);
+int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int reps, double *ms_avg, double *alg_bytes);
 int sbtv_diag_prox_variant(sbtv_ctx *ctx, int M, int N, int batch, int out[6]);
 
 #ifdef __cplusplus

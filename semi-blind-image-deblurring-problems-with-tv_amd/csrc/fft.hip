@@ -942,4 +942,115 @@ int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *
     return canary_epilogue(ctx, 0);
 }
 
+// ---- diagnostics: time ONE pass of the hot path on scratch data (bench.py's per-kernel roofline lines and the
+// kernel tuning harness tools/fft_lab.py).  HIP events on the context stream, `reps` back-to-back launches after two
+// untimed ones; *alg_bytes = algorithmic bytes of one launch.
+namespace sbtv {
+__global__ void diag_fill_kernel(double *__restrict__ x, size_t n, unsigned salt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned h = ((unsigned)i * 2654435761u + salt) * 2246822519u;
+        x[i] = (double)(h >> 8) * (255.0 / 16777216.0);          // [0, 255)
+    }
+}
+static int diag_fill(sbtv_ctx *ctx, double *x, size_t n, unsigned salt) {
+    hipLaunchKernelGGL(diag_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, x, n, salt);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+}  // namespace sbtv
+
+int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int reps, double *ms_avg, double *alg_bytes) {
+    if (!ctx || !ms_avg || reps < 1 || batch < 1) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    FftPlan pl;
+    SBTV_TRY(fft_plan(ctx, M, N, batch, &pl));
+    const size_t P = (size_t)M * N, cnt = P * batch, spec = (size_t)(pl.n1 + 1) * N * batch;
+    double *u = nullptr, *bu = nullptr, *g = nullptr, *tru = nullptr, *x = nullptr, *mu_d = nullptr, *taps_d = nullptr;
+    double2 *S = nullptr, *H = nullptr, *Y = nullptr, *D1 = nullptr, *D2 = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "diag.u", cnt, &u));
+    SBTV_TRY(ws_get_t(ctx, "diag.bu", cnt, &bu));
+    SBTV_TRY(ws_get_t(ctx, "diag.g", cnt, &g));
+    SBTV_TRY(ws_get_t(ctx, "diag.tru", cnt, &tru));
+    SBTV_TRY(ws_get_t(ctx, "diag.x", cnt, &x));
+    SBTV_TRY(ws_get_t(ctx, "diag.S", cnt / 2, &S));
+    SBTV_TRY(ws_get_t(ctx, "diag.H", spec, &H));
+    SBTV_TRY(ws_get_t(ctx, "diag.Y", spec, &Y));
+    SBTV_TRY(ws_get_t(ctx, "diag.D1", spec, &D1));
+    SBTV_TRY(ws_get_t(ctx, "diag.D2", spec, &D2));
+    SBTV_TRY(ws_get_t(ctx, "diag.mu", (size_t)batch, &mu_d));
+    SBTV_TRY(ws_get_t(ctx, "diag.taps", (size_t)batch * 49, &taps_d));
+    const int nrb = fft_rows_blocks(pl), npb = fft_cols_blocks(pl);
+    double *acc = nullptr, *postp = nullptr, *lam_d = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "diag.acc", (size_t)batch * 3 * nrb, &acc));
+    SBTV_TRY(ws_get_t(ctx, "diag.post", (size_t)batch * 6 * npb, &postp));
+    SBTV_TRY(ws_get_t(ctx, "diag.lam", (size_t)batch, &lam_d));
+    {
+        std::vector<double> h((size_t)batch * 49), m(batch, 0.003), l(batch, 6.0);
+        const double p[3] = {0.4, 0.3, 0.0};
+        SBTV_TRY(sbtv_psf_taps(SBTV_PSF_GAUSSIAN, 7, p, h.data(), nullptr, nullptr));
+        for (int b = 1; b < batch; ++b) std::copy(h.begin(), h.begin() + 49, h.begin() + (size_t)b * 49);
+        SBTV_HIP(ctx, hipMemcpyAsync(taps_d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(mu_d, m.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(lam_d, l.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    SBTV_TRY(diag_fill(ctx, u, cnt, 1));
+    SBTV_TRY(diag_fill(ctx, bu, cnt, 2));
+    SBTV_TRY(diag_fill(ctx, g, cnt, 3));
+    SBTV_TRY(diag_fill(ctx, tru, cnt, 4));
+    SBTV_TRY(diag_fill(ctx, reinterpret_cast<double *>(S), cnt, 5));
+    SBTV_TRY(psf_spectrum(ctx, pl, taps_d, 7, H));
+    SBTV_TRY(diag_fill(ctx, reinterpret_cast<double *>(Y), 2 * spec, 6));
+    SBTV_TRY(psf_spectrum(ctx, pl, taps_d, 7, D1));
+    SBTV_TRY(psf_spectrum(ctx, pl, taps_d, 7, D2));
+    ProxPlan pp;
+    if (pass == 7 || pass == 8) SBTV_TRY(prox_plan(ctx, M, N, batch, &pp, "diag.prox"));
+    const double inv_scale = 1.0 / ((double)pl.n1 * N);
+    const double specb = 16.0 * (double)(pl.n1 + 1) * N * batch, img = 8.0 * (double)cnt;
+    double bytes = 0.0;
+    auto once = [&]() -> int {
+        RowsArgs a{};
+        a.H = H;
+        a.Y = Y;
+        a.D1 = D1;
+        a.D2 = D2;
+        a.mu = mu_d;
+        a.acc = acc;
+        switch (pass) {
+            case 0: bytes = 3 * img; return fft_cols_fwd(ctx, pl, u, bu, S);
+            case 1: a.dir_fwd = a.dir_inv = 1; a.op = OP_SALSA; bytes = 2 * img + 2 * specb; return fft_rows(ctx, pl, S, S, a);
+            case 2: {
+                ColsPost cp;
+                cp.u = u; cp.bu = bu; cp.g = g; cp.tru = tru; cp.partials = postp;
+                bytes = 7 * img;
+                return fft_cols_inv_post(ctx, pl, S, x, inv_scale, nullptr, cp);
+            }
+            case 3: bytes = 2 * img; return fft_cols_inv(ctx, pl, S, x, inv_scale);
+            case 4: a.dir_fwd = 1; a.op = OP_NONE; bytes = 2 * img; return fft_rows(ctx, pl, S, S, a);
+            case 5: a.dir_fwd = a.dir_inv = 1; a.op = OP_GRAD; bytes = 2 * img + 4 * specb; return fft_rows(ctx, pl, S, S, a);
+            case 6: a.dir_fwd = a.dir_inv = 1; a.op = OP_GRADF; bytes = 2 * img + 2 * specb; return fft_rows(ctx, pl, S, S, a);
+            case 7:     // warm-started prox(10) with f, as in one SALSA outer iteration (2 fused launches + control)
+                bytes = (40.0 * 10 + 8.0) * (double)cnt;
+                SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, 10, 1e-3, 0.249, true, nullptr));
+                return prox_iterate(ctx, pp, g, 10, x, false);
+            case 8:     // cold prox(25) with f, as in one SAPG / FISTA iteration
+                bytes = (40.0 * 25 + 8.0) * (double)cnt;
+                SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, 25, 1e-3, 0.249, false, nullptr));
+                return prox_iterate(ctx, pp, g, 25, x, true);
+            default: return fail(ctx, SBTV_ERR_BADARG, "sbtv_diag_time_pass: unknown pass");
+        }
+    };
+    if (pass == 7) SBTV_TRY(prox_zero_duals(ctx, pp));
+    for (int w = 0; w < 2; ++w) SBTV_TRY(once());
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    for (int r = 0; r < reps; ++r) SBTV_TRY(once());
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    *ms_avg = (double)ms / reps;
+    if (alg_bytes) *alg_bytes = bytes;
+    return canary_epilogue(ctx, 0);
+}
+
 }  // extern "C"

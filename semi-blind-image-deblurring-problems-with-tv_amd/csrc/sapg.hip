@@ -735,8 +735,10 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     }
     SBTV_TRY(upload_lam_sigma(theta));
     SBTV_TRY(do_prox(false));                                      // proxGX = proxG(X, thetas(1))   (:134)
-    for (int ii = 2; ii <= samples; ++ii) {
-        const int i0 = ii - 1;
+    // device work of SAPG iteration ii up to the scalars it needs on the host.  In the shared-gradient mode a failure
+    // here must not return at once: the peer ranks are about to enter this iteration's all-reduce and would wait
+    // for ever, so the status travels with the gradients (sixth reduced element) and every rank leaves together.
+    auto iterate_device = [&](int ii) -> int {
         bool replayed = false;
         if (use_graph && ii >= 3) SBTV_TRY(graph_iteration(&g_main, true, theta, &replayed));
         // gradF(X, p(ii-1), sigma(ii-1)): `grad` already holds AT(AX-y) for the current spectra unless
@@ -762,10 +764,16 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_TRY(operator_pass(!params_move));                                                 // G_w*, G_s, f  (:170-188)
             SBTV_TRY(fetch_scalars());                                                             // incl. g(X)  (:165)
         }
+        return 0;
+    };
+    for (int ii = 2; ii <= samples; ++ii) {
+        const int i0 = ii - 1;
+        const int rc_dev = iterate_device(ii);
+        if (rc_dev != 0 && !(shared && reduce_fn)) return rc_dev;
         const double delta = op->d_scale * (pow((double)ii, -op->d_exp) / dimX);              // :55
         // per-chain gradients
         std::vector<double> Gt(batch), Gp0(batch), Gp1(batch), Gs(batch);
-        for (int b = 0; b < batch; ++b) {
+        for (int b = 0; b < batch && rc_dev == 0; ++b) {
             const double resid2 = scal_h[(size_t)b * 3] * parseval;
             const double tv = scal_h[3 * (size_t)batch + b];
             Gt[b] = dimX / theta[b] - tv;                                                      // :165
@@ -778,11 +786,15 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         if (shared) {
             // all chains sample the same posterior: average their gradients (the reference's
             // `for jj=1:1 ... G = mean(g_*)`, SAPG_algorithm_moffat.m:158-173), across ranks too
-            double buf[5] = {0, 0, 0, 0, (double)batch};
-            for (int b = 0; b < batch; ++b) { buf[0] += Gt[b]; buf[1] += Gp0[b]; buf[2] += Gp1[b]; buf[3] += Gs[b]; }
+            // [sum G_theta, sum G_p0, sum G_p1, sum G_sigma, chains, ranks that failed in this iteration]
+            double buf[6] = {0, 0, 0, 0, (double)batch, rc_dev != 0 ? 1.0 : 0.0};
+            for (int b = 0; b < batch && rc_dev == 0; ++b) { buf[0] += Gt[b]; buf[1] += Gp0[b]; buf[2] += Gp1[b]; buf[3] += Gs[b]; }
             if (reduce_fn) {
-                int rc = reduce_fn(reduce_user, buf, 5);
+                int rc = reduce_fn(reduce_user, buf, 6);
+                if (rc_dev != 0) return rc_dev;            // the local error, after the peers have been told
                 if (rc != 0) return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: reduce_fn failed");
+                if (buf[5] != 0.0)
+                    return fail(ctx, SBTV_ERR_PEER, "SAPG_algorithm: a peer rank of the shared-gradient chains failed in this iteration");
             }
             for (int b = 0; b < batch; ++b) { Gt[b] = buf[0] / buf[4]; Gp0[b] = buf[1] / buf[4]; Gp1[b] = buf[2] / buf[4]; Gs[b] = buf[3] / buf[4]; }
         }

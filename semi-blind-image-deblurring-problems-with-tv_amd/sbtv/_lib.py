@@ -22,7 +22,7 @@ ERRORS = {
     -1: "SBTV_ERR_BADARG", -2: "SBTV_ERR_SIZE", -3: "SBTV_ERR_MAXITER", -4: "SBTV_ERR_DUALVARS",
     -5: "SBTV_ERR_MODE", -6: "SBTV_ERR_STOPCRITERION", -7: "SBTV_ERR_INIT", -8: "SBTV_ERR_MISSING_AT",
     -9: "SBTV_ERR_MISSING_LS", -10: "SBTV_ERR_PSF", -11: "SBTV_ERR_NOMEM", -12: "SBTV_ERR_NODEVICE",
-    -13: "SBTV_ERR_CANARY",
+    -13: "SBTV_ERR_CANARY", -14: "SBTV_ERR_PEER",
 }
 
 
@@ -97,6 +97,7 @@ SIGNATURES = {
     "sbtv_MSE": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
+    "sbtv_diag_time_pass": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
 }
 
 _lib = None
@@ -181,6 +182,16 @@ class Context:
         en, nb, bad = _I(0), _I(0), _I(0)
         self.check(self.lib.sbtv_diag_canary(self.h, int(bool(poke)), C.byref(en), C.byref(nb), C.byref(bad)))
         return dict(enabled=bool(en.value), buffers=nb.value, bad_bytes=bad.value)
+
+    PASSES = {"cols_fwd": 0, "rows_salsa": 1, "cols_inv_post": 2, "cols_inv": 3, "rows_fwd": 4, "rows_grad": 5,
+              "rows_gradf": 6, "prox10_warm": 7, "prox25_cold": 8}
+
+    def time_pass(self, name, M, N, batch=1, reps=20):
+        """Average ms per launch and algorithmic bytes of one pass of the hot path (sbtv_diag_time_pass)."""
+        ms, by = _D(0.0), _D(0.0)
+        self.check(self.lib.sbtv_diag_time_pass(self.h, self.PASSES[name], int(M), int(N), int(batch), int(reps),
+                                                C.byref(ms), C.byref(by)))
+        return dict(ms=ms.value, bytes=by.value, gbs=by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0)
 
     def prox_variant(self, M, N, batch=1):
         """Which TV-prox kernel an M x N x batch problem takes (sbtv_diag_prox_variant)."""

@@ -53,9 +53,16 @@ def shard(n_items, rank=None, world=None):
 
 def split_chains(n_chains, rank=None, world=None):
     """Number of MYULA chains this rank runs and the index of its first chain: pass them to the SAPG call as
-    op["chains"] and op["chain_offset"] so that chain b draws the Philox stream chain_offset + b."""
+    op["chains"] and op["chain_offset"] so that chain b draws the Philox stream chain_offset + b.
+
+    Every rank must own at least one chain: a rank without chains could not make the SAPG call and the others
+    would wait for it in the per-iteration all-reduce.  n_chains and world are the same on all ranks, so this check
+    raises on all of them together."""
     if rank is None or world is None:
         rank, world = rank_world()
+    if n_chains < world:
+        raise ValueError(f"shared-gradient SAPG needs at least one chain per rank: {n_chains} chains on {world} ranks "
+                         "(use fewer ranks or more chains)")
     base, extra = divmod(n_chains, world)
     mine = base + (1 if rank < extra else 0)
     first = rank * base + min(rank, extra)
@@ -84,24 +91,33 @@ def merge_sharded(n_items, per_rank_lists):
 
 
 def make_allreduce_fn():
-    """A `reduce_fn` for sbtv_SAPG_algorithm(share_gradients=1): sums `buf[0:n]` over all ranks in place.
-    RCCL needs a device tensor; the payload is 40 bytes, so the staging copy is noise."""
+    """A `reduce_fn` for sbtv_SAPG_algorithm(share_gradients=1): sums `buf[0:n]` (n = 6: four gradient sums, the
+    chain count and the failed-rank flag) over all ranks in place.  RCCL needs a device tensor: one persistent
+    8-double device buffer and one pinned host buffer are kept for the life of the callback, so an iteration costs
+    two 48-byte copies and the collective, no allocation."""
     import torch
     import torch.distributed as dist
     r, w = rank_world()
     if w == 1:
         return None
     use_cuda = dist.get_backend() == "nccl"
+    host = torch.zeros(8, dtype=torch.float64)
+    if use_cuda:
+        host = host.pin_memory()
+        dev = torch.zeros(8, dtype=torch.float64, device="cuda")
 
     def fn(user, buf, n):
         try:
-            t = torch.tensor([buf[i] for i in range(n)], dtype=torch.float64)
-            if use_cuda:
-                t = t.cuda()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t = t.cpu()
             for i in range(n):
-                buf[i] = float(t[i])
+                host[i] = buf[i]
+            if use_cuda:
+                dev.copy_(host, non_blocking=True)
+                dist.all_reduce(dev, op=dist.ReduceOp.SUM)
+                host.copy_(dev)                       # synchronising copy: the sums are needed on the host now
+            else:
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            for i in range(n):
+                buf[i] = float(host[i])
             return 0
         except Exception:      # never raise through the C boundary
             return 1

@@ -31,8 +31,8 @@ def _worker(rank, world, port, q):
     # 2) 5 chains on one image: chain split + the per-iteration all-reduce of [G_t, G_p0, G_p1, G_s, n]
     nch, first = sd.split_chains(5)
     fn = sd.make_allreduce_fn()
-    buf = (C.c_double * 5)(*[float(first + k + 1) for k in range(4)], float(nch))
-    rc = fn(None, buf, 5)
+    buf = (C.c_double * 6)(*[float(first + k + 1) for k in range(4)], float(nch), float(rank == 1))
+    rc = fn(None, buf, 6)
     sd.barrier()
     q.put((rank, mine, merged, nch, first, rc, list(buf)))
 
@@ -56,6 +56,7 @@ def test_world2_gloo_sharding_and_allreduce():
     assert rc0 == rc1 == 0 and b0 == b1
     assert b0[4] == 5.0                                   # total number of chains
     assert b0[0] == (0 + 1) + (3 + 1)                     # sums over ranks
+    assert b0[5] == 1.0                                   # the failed-rank flag of rank 1 reaches both ranks
 
 
 def test_single_process_helpers():
@@ -68,3 +69,25 @@ def test_single_process_helpers():
     assert sum(sd.split_chains(10, r, 4)[0] for r in range(4)) == 10
     assert sd.merge_sharded(5, [[0, 2, 4], [1, 3]]) == [0, 1, 2, 3, 4]
     assert sd.make_allreduce_fn() is None
+    # a rank without chains would never enter the per-iteration all-reduce: refused identically on every rank
+    for r in range(4):
+        with pytest.raises(ValueError):
+            sd.split_chains(3, r, 4)
+    assert [sd.split_chains(4, r, 4) for r in range(4)] == [(1, r) for r in range(4)]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run launches the two ranks itself (as a child
+    `python -m torch.distributed.run`, never an exec of a process that touched the GPU); --dry-run keeps the
+    ranks off the GPU so the launch path can be checked here."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] and d["max_elapsed_s"] == 0.002

@@ -123,7 +123,7 @@ def test_sapg_shared_gradient_chains_and_philox(ctx):
         return 0
     out = sbtv.SAPG_algorithm_Guassian(st["y"], op, c, share_gradients=True, reduce_fn=reduce_fn)
     res = out[-1]
-    assert len(res) == 4 and len(calls) == samples - 1 and set(calls) == {5}
+    assert len(res) == 4 and len(calls) == samples - 1 and set(calls) == {6}
     for r in res[1:]:                  # identical parameter trajectories on every chain
         np.testing.assert_array_equal(r["thetas"], res[0]["thetas"])
         np.testing.assert_array_equal(r["sigmas"], res[0]["sigmas"])
@@ -417,11 +417,11 @@ def _sapg_vs_oracle(kind, x, samples, warmup, burnIn, p_init=None, fix=None, see
     np.testing.assert_allclose(res["sigmas"], ref["sigmas"], rtol=1e-9)
     for q, nm in enumerate(names):
         np.testing.assert_allclose(res[nm + "s"], ref["ps"][q], rtol=1e-8)
-        assert ref["ps"][q][-1] != ref["ps"][q][0], "the PSF parameter must move in this test"
         # gradients <dA_q X, AX - y>/sigma^2: a sum over the spectrum with cancellation, so a relative bar on
         # the scale of the terms (Parseval form vs the reference's spatial sum)
         np.testing.assert_allclose(res["grad_" + nm][1:], ref["grads"][1 + q][1:], rtol=grad_rtol,
                                    atol=grad_rtol * np.max(np.abs(ref["grads"][1 + q])))
+    assert any(ref["ps"][q][-1] != ref["ps"][q][0] for q in range(len(names))), "a PSF parameter must move in this test"
     np.testing.assert_allclose(res["grad_theta"][1:], ref["grads"][0][1:], rtol=1e-9)
     np.testing.assert_allclose(res["grad_sigma"][1:], ref["grads"][len(names) + 1][1:], rtol=1e-8)
     np.testing.assert_allclose(res["logPiTraceX"], ref["logPiTraceX"], rtol=1e-9)
@@ -487,9 +487,31 @@ def test_sapg_shared_gradient_chains_match_oracle(ctx):
             np.testing.assert_allclose(res[k]["sigmas"], ref["sigmas"], rtol=1e-9)
             for q, nm in enumerate(names):
                 np.testing.assert_allclose(res[k][nm + "s"], ref["ps"][q], rtol=1e-8)
-                assert ref["ps"][q][-1] != ref["ps"][q][0]
+            assert any(ref["ps"][q][-1] != ref["ps"][q][0] for q in range(len(names)))
             np.testing.assert_allclose(res[k]["grad_theta"][1:], ref["grads"][0][1:], rtol=1e-9)
             np.testing.assert_allclose(res[k]["logPiTraceX"], ref["logPiTraceX"][k], rtol=1e-9)
             np.testing.assert_allclose(res[k]["gXTrace"][:-1], ref["gXTrace"][k][:-1], rtol=1e-10)
             np.testing.assert_allclose(res[k]["Xlast_sample"], ref["Xlast_samples"][k], rtol=1e-8, atol=1e-8)
         assert np.max(np.abs(res[0]["Xlast_sample"] - res[1]["Xlast_sample"])) > 1e-3
+
+
+def test_sapg_shared_chains_peer_failure_is_reported_not_waited_for(ctx):
+    """The 6th reduced element counts ranks whose iteration failed: a rank that sees it non-zero after the
+    all-reduce returns SBTV_ERR_PEER instead of going on alone (a failing rank still joins the collective first,
+    sapg.hip `iterate_device`), so no rank is left waiting inside the next all-reduce."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    x = synth_image(M, N, 3)
+    st = o.demo_setup("gaussian", x, np.random.default_rng(2).standard_normal((M, N)), evMax=0.99)
+    op, c, names = _op_struct("gaussian", st, 8, 3, 4)
+    calls = []
+
+    def reduce_fn(user, buf, n):
+        calls.append(n)
+        if len(calls) == 3:
+            buf[5] += 1.0             # what the sum over ranks looks like when a peer failed in this iteration
+        return 0
+    with pytest.raises(sbtv.SbtvError) as e:
+        sbtv.SAPG_algorithm_Guassian(st["y"], dict(op, chains=2), c, share_gradients=True, reduce_fn=reduce_fn)
+    assert e.value.code == -14 and len(calls) == 3

@@ -6,9 +6,12 @@ from conftest import synth_image
 
 pytestmark = pytest.mark.gpu
 
-# The TV kernels are compiled with fp contraction off and use IEEE sqrt/div, so
-# element-wise results agree with the NumPy oracle to a few ulp; only the
-# reduction order (err, TVnorm) differs.
+# Arithmetic: the default build of the fused kernels is FAST (v_rcp_f64 / v_rsq_f64 seeds refined by Newton /
+# Goldschmidt steps, FMA contraction on): every operation stays within ~1 ulp of the IEEE result the NumPy oracle
+# computes, and the dual iteration is non-expansive, so element-wise results agree to ~1e-14; the one-iteration
+# kernels (odd M) and SBTV_EXACT=1 use IEEE sqrt / div with contraction off.  The reduction order of err / TVnorm
+# differs from NumPy's in every build.  These sizes take the one-row-per-lane fused kernel (fewer than 256 tiles)
+# or the scalar kernel; the two-rows-per-lane kernel that large images take is covered by test_gpu_tv_large.py.
 TOL = dict(rtol=1e-12, atol=1e-12)
 
 

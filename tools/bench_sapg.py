@@ -11,14 +11,39 @@ Under torch.distributed.run the same script runs the whole configuration, one ra
             all-reduce of 5 doubles per SAPG iteration (sbtv.dist.make_allreduce_fn = RCCL with the nccl backend).
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_sapg.py --config 5
   (--backend gloo --all-ranks-on-device0 rehearses the multi-rank path on a one-GPU box)
+`--gpus N` outside torch.distributed.run starts the N ranks itself (child `python -m torch.distributed.run`, before
+this process imports torch).  Rank 0 prints prose on stderr and ONE JSON line on stdout:
+  {"metric", "value" (image-iterations/s over all ranks), "unit", "n_gpus", "world_size_seen" (size of the process group
+   the collective ran on), "backend", "ms_per_iteration" (max over ranks), "config": {...}, "scaling": "weak"}
 """
 import argparse
+import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd"))
+
+
+def _self_launch(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _n = [int(sys.argv[i + 1]) for i, v in enumerate(sys.argv[:-1]) if v == "--gpus"]
+    if _n and _n[0] > 1:
+        sys.exit(_self_launch(_n[0]))          # nothing here has imported torch or touched a GPU
+
 import numpy as np
 import sbtv
 
@@ -52,6 +77,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--total", type=int, default=0, help="images (config 4, default 64) / chains (config 5, default 32) "
                                                          "over all ranks; single process default: one GPU's share")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
     ap.add_argument("--backend", default=None)
     ap.add_argument("--all-ranks-on-device0", action="store_true")
     a = ap.parse_args()
@@ -72,7 +98,13 @@ def main():
         out = sbtv.my_fista(yd, A, A.T, tau, 1.0, sbtv.TVnorm, sbtv.Psi_TV(25), 1, -1.0, a.iters, xd)
         dt = time.perf_counter() - t0
         print(f"config 3: FISTA + TV prox(25), 2048^2 Moffat: {(a.iters - 1) / dt:.1f} iterations/s "
-              f"({1e3 * dt / (a.iters - 1):.3f} ms/iteration), objective {out[1][0]:.4e} -> {out[1][-1]:.4e}")
+              f"({1e3 * dt / (a.iters - 1):.3f} ms/iteration), objective {out[1][0]:.4e} -> {out[1][-1]:.4e}",
+              file=sys.stderr)
+        print(json.dumps({"metric": "FISTA + TV prox(25) iterations/s, 2048x2048 Moffat PSF (BASELINE configs[2])",
+                          "value": (a.iters - 1) / dt, "unit": "FISTA iterations/s", "n_gpus": 1,
+                          "ms_per_iteration": 1e3 * dt / (a.iters - 1), "dtype": "f64", "data": "synthetic",
+                          "higher_is_better": True, "config": {"workload": "my_fista + cold Chambolle(25)",
+                                                               "image": [2048, 2048]}}), flush=True)
         return
     if a.config == 4:
         kind, size, share = "laplace", 1024, False
@@ -102,6 +134,12 @@ def main():
     ctx.sync()
     sd.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:                                # the slowest rank defines the iteration time
+        import torch
+        import torch.distributed as tdist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if tdist.get_backend() == "nccl" else "cpu")
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
     it = samples - 1
     thetas = [float(np.ravel(r["thetas"])[-1]) for r in out[-1]] if isinstance(out[-1], list) else [float(out[-1]["thetas"][-1])]
     allth = sd.gather_objects(thetas)
@@ -110,10 +148,30 @@ def main():
         print(f"config {a.config}: SAPG {kind}, {total} x {size}^2 {unit} on {world} rank(s) ({nimg} per rank): "
               f"{it / dt:.2f} SAPG iterations/s ({1e3 * dt / it:.2f} ms/iteration, "
               f"{1e3 * dt / it / nimg:.2f} ms per local image-iteration), "
-              f"{total * it / dt:.0f} image-iterations/s in total")
+              f"{total * it / dt:.0f} image-iterations/s in total", file=sys.stderr)
+        same = None
         if share:
             flat = [t for part in allth for t in part]
-            print(f"  last theta of every chain equal across ranks: {max(flat) - min(flat) == 0.0} ({flat[0]:.6g})")
+            same = (max(flat) - min(flat) == 0.0)
+            print(f"  last theta of every chain equal across ranks: {same} ({flat[0]:.6g})", file=sys.stderr)
+        import torch.distributed as tdist
+        live = tdist.is_available() and tdist.is_initialized()
+        print(json.dumps({
+            "metric": ("SAPG chain-iterations/s, 32 MYULA chains with shared gradients on one 2048x2048 image "
+                       "(BASELINE configs[4])" if share else
+                       "SAPG image-iterations/s, batch of 64 independent 1024x1024 images, Laplace PSF "
+                       "(BASELINE configs[3])"),
+            "value": total * it / dt, "unit": ("chain" if share else "image") + "-iterations/s", "n_gpus": world,
+            "world_size_seen": tdist.get_world_size() if live else 1,
+            "backend": tdist.get_backend() if live else None,
+            "steps": it, "ms_per_iteration": 1e3 * dt / it, "ms_per_local_unit_iteration": 1e3 * dt / it / nimg,
+            "higher_is_better": True, "scaling": "weak" if a.total == 0 and world == 1 else "strong",
+            "dtype": "f64", "data": "synthetic",
+            "collective": ("all-reduce of 6 doubles per iteration (sbtv.dist.make_allreduce_fn)" if share and world > 1
+                           else "none"),
+            "chains_agree_across_ranks": same,
+            "config": {"workload": f"SAPG {kind}, chambolleit=25, {total} x {size}^2 {unit}", "image": [size, size],
+                       "units_total": total, "units_per_rank": nimg, "parallelism": f"{unit} x{world}"}}), flush=True)
     sd.barrier()
 
 
