@@ -12,10 +12,14 @@
  * Conventions
  *   - all image buffers are IEEE double, column-major (MATLAB layout):
  *     element (i,j) of image b lives at  buf[b*M*N + j*M + i],  M rows, N cols.
- *   - M and N must be powers of two, 16 <= M <= 4096, 16 <= N <= 4096, for every
- *     entry point that applies the blur operator (hand-written radix-2^k FFT).
- *     The TV entry points (prox, TVnorm) accept any M >= 2, N >= 2 (even M takes
- *     the fused 16-byte-per-lane kernels, odd M a scalar one-iteration kernel).
+ *   - image sizes: 2 <= M, N <= 4096 for every entry point that applies the blur
+ *     operator (SBTV_ERR_SIZE otherwise).  Powers of two from 16 take the tuned radix-2^k
+ *     real-FFT kernels; any other size runs like the reference's fft2 closures do
+ *     (utils/resize.m:1-12) through a chirp-z (Bluestein) complex transform, several
+ *     times slower.  FISTA, SAPG / MYULA, max_eigenval, C-SALSA and CoRAL additionally
+ *     need an even number of pixels.  The TV entry points (prox, TVnorm) accept any
+ *     M >= 2, N >= 2 (even M takes the fused 16-byte-per-lane kernels, odd M a scalar
+ *     one-iteration kernel).
  *   - `flags & SBTV_DEVICE_PTRS`: image buffers are device pointers on the
  *     context's GPU (no PCIe copies; asynchronous on the context stream).
  *     Otherwise they are host pointers and the call copies in/out and returns
@@ -44,7 +48,7 @@ extern "C" {
 /* status codes */
 #define SBTV_OK                   0
 #define SBTV_ERR_BADARG          -1   /* generic bad argument                                  */
-#define SBTV_ERR_SIZE            -2   /* unsupported image size (non power of two for the FFT) */
+#define SBTV_ERR_SIZE            -2   /* unsupported image size (outside 2..4096, or an odd pixel count where noted) */
 #define SBTV_ERR_MAXITER         -3   /* chambolle: 'maxiter' missing  (chambolle_prox_TV_stop.m:95,131, quirk Q1) */
 #define SBTV_ERR_DUALVARS        -4   /* 'Wrong size of the dual variables' (chambolle_prox_TV_stop.m:103)          */
 #define SBTV_ERR_MODE            -5   /* 'The value of parameter mode must be 1 or 2' (A_wrapper.m:15)              */

@@ -193,11 +193,13 @@ struct AdmmCommon {
 };
 
 int admm_common(sbtv_ctx *ctx, int M, int N, const double *taps, int taille, const double *yd, AdmmCommon *c) {
+    if (((size_t)M * N) & 1)
+        return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
     SBTV_TRY(fft_plan(ctx, M, N, 1, &c->fp));
     c->P = (size_t)M * N;
-    SBTV_TRY(ws_get_t(ctx, "admm.S", c->P / 2, &c->S));
-    SBTV_TRY(ws_get_t(ctx, "admm.H", (size_t)(c->fp.n1 + 1) * N, &c->Hs));
-    SBTV_TRY(ws_get_t(ctx, "admm.Y", (size_t)(c->fp.n1 + 1) * N, &c->Ys));
+    SBTV_TRY(ws_get_t(ctx, "admm.S", c->fp.s_img, &c->S));
+    SBTV_TRY(ws_get_t(ctx, "admm.H", c->fp.u_img, &c->Hs));
+    SBTV_TRY(ws_get_t(ctx, "admm.Y", c->fp.u_img, &c->Ys));
     SBTV_TRY(ws_get_t(ctx, "admm.taps", (size_t)taille * taille, &c->taps_d));
     SBTV_HIP(ctx, hipMemcpyAsync(c->taps_d, taps, sizeof(double) * taille * taille, hipMemcpyHostToDevice, ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -278,7 +280,7 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
     SBTV_TRY(ws_get_t(ctx, "admm.par", (size_t)4, &par));               // mu1, mu2, 1/mu1
     SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
     SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)16, &sums));            // [0..5] update sums, [6] TV(x), [8] n_ve^2
-    SBTV_TRY(ws_get_t(ctx, "admm.W", (size_t)(c.fp.n1 + 1) * N, &Ws));
+    SBTV_TRY(ws_get_t(ctx, "admm.W", c.fp.u_img, &Ws));
     double *hs = nullptr;
     {
         void *pz = nullptr;

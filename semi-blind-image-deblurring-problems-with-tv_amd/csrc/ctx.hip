@@ -1,4 +1,5 @@
 // Context, workspaces, staging, twiddle tables and the host-side PSF tap builders.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -232,6 +233,49 @@ int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count,
     return 0;
 }
 
+// ---- host waits inside the solver loops -----------------------------------------------------------------
+// One outer iteration of a small image takes tens of microseconds; a host thread that blocks in
+// hipEventSynchronize / hipStreamSynchronize is woken much later than that and the GPU queue runs dry.  These
+// helpers can poll (hipEventQuery / hipStreamQuery) for up to 2 ms before they fall back to the blocking call.
+// Opt-in (SBTV_SPIN=1): measured on MI355X it helps at 512^2 (8 500 vs 6 500 SALSA iterations/s) and hurts at 256^2
+// and 1024^2 (profiles/r02_small_sizes.md) - the polling calls compete with the launches of the same thread.
+static inline bool spin_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_SPIN");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+template <class Q>
+static inline hipError_t poll_2ms(Q query) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        if ((it & 63) == 63 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3)
+            return hipErrorNotReady;
+    }
+}
+int wait_event(sbtv_ctx *ctx, hipEvent_t ev) {
+    if (spin_enabled()) {
+        const hipError_t e = poll_2ms([&] { return hipEventQuery(ev); });
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail_hip(ctx, e, "hipEventQuery", __FILE__, __LINE__);
+    }
+    SBTV_HIP(ctx, hipEventSynchronize(ev));
+    return 0;
+}
+int wait_stream(sbtv_ctx *ctx) {
+    if (spin_enabled()) {
+        const hipError_t e = poll_2ms([&] { return hipStreamQuery(ctx->stream); });
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail_hip(ctx, e, "hipStreamQuery", __FILE__, __LINE__);
+    }
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // ---- hipGraph replay of launch-bound iteration bodies -------------------------------------------
 // Small images make the solver loops latency-bound (20-odd dependent kernels of a few microseconds per
 // iteration).  With SBTV_GRAPH=1 the iteration body is captured once from the stream and replayed with one
@@ -332,6 +376,7 @@ int sbtv_ctx_destroy(sbtv_ctx *ctx) {
     if (ctx->canary_desc) (void)hipFree(ctx->canary_desc);
     if (ctx->canary_bad) (void)hipFree(ctx->canary_bad);
     for (auto &kv : ctx->twiddles) (void)hipFree(kv.second);
+    for (auto &kv : ctx->any_axes) (void)hipFree(kv.second);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);

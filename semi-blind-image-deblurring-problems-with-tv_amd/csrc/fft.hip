@@ -20,6 +20,8 @@
 // The first stage reads global memory directly in its natural coalesced order
 // and the last stage leaves the result in the same register slots, so global
 // stores are coalesced too.
+#include <type_traits>
+
 #include "sbtv_internal.h"
 
 namespace sbtv {
@@ -38,6 +40,14 @@ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {   // a * conj(b
 __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
 __device__ __forceinline__ double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
 __device__ __forceinline__ double cabs2(double2 a) { return a.x * a.x + a.y * a.y; }
+
+// Tiled packed-spectrum layout of the sizes that take the wave-granular column kernels (fft_wave.inc):
+// S[(l / TW)][k][l % TW], i.e. 64-byte pieces of 4 columns of one row k.
+constexpr int TWS = 2;                    // log2 of the tile width
+constexpr int TW = 1 << TWS;
+__device__ __forceinline__ size_t s_tiled(int k, int l, int n1) {
+    return (((size_t)(l >> TWS) * n1 + k) << TWS) + (l & (TW - 1));
+}
 
 template <bool INV>
 __device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int idx) {
@@ -420,6 +430,8 @@ struct RowsParams {
     int n1;                 // rows of S per image
     int fwd, inv, op;
     int shared_spec;        // 1: H / Y / D1 / D2 hold ONE spectrum shared by every image of the batch
+    size_t u_img;           // elements of one operator spectrum per image
+    int u_ld;               // leading dimension of the row-major operator spectra (tiled mode)
 };
 
 template <int OP>
@@ -461,7 +473,9 @@ __device__ __forceinline__ double2 spec_apply(double2 V, double2 H, double2 Y, d
     }
 }
 
-template <int LOG2N, int RK, int OP>
+// TILED: S is in the tiled layout (a workgroup's RK rows x 4 columns are then 64 RK contiguous bytes) and the operator
+// spectra are row-major U[k][l] (fft_wave.inc); otherwise S[l][k] and U[l][k].
+template <int LOG2N, int RK, int OP, bool TILED = false>
 __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsParams p) {
     constexpr int N = 1 << LOG2N, T = N / 8;
     constexpr int LDSI = RK * N;
@@ -486,13 +500,15 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     const double2 *__restrict__ in = p.Sin + ibase;
     RowsX<RK> X{lds, LDSN, q};
     double2 v[8];
+    auto sidx = [&](int l) -> size_t { return TILED ? s_tiled(k, l, n1) : (size_t)l * n1 + k; };
+    auto uidx = [&](int kk, int l) -> size_t { return (size_t)l * (n1 + 1) + kk; };
 #pragma unroll
-    for (int s = 0; s < 8; ++s) v[s] = in[(size_t)(t + s * T) * n1 + k];
+    for (int s = 0; s < 8; ++s) v[s] = in[sidx(t + s * T)];
     if (p.fwd) fft_stages<LOG2N, 0, false>(v, t, p.tw, X);
 
     double acc[3] = {0.0, 0.0, 0.0};
     if constexpr (OP != OP_NONE) {
-        const size_t hbase = p.shared_spec ? 0 : (size_t)b * (n1 + 1) * N;
+        const size_t hbase = p.shared_spec ? 0 : (size_t)b * p.u_img;
         const double mu = p.mu ? p.mu[b] : 0.0;
         constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF);
         constexpr bool needD = (OP == OP_GRAD);
@@ -503,7 +519,8 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int l = t + s * T;
-                const size_t hi = hbase + (size_t)l * (n1 + 1);
+                const size_t hi = hbase + uidx(0, l);
+                const size_t hin = hbase + uidx(n1, l), hik = hbase + uidx(k, l);
                 if (q == 0) {
                     const double2 P = v[s], Q = cconj(m[s]);
                     const double2 A = cscale(cadd(P, Q), 0.5);
@@ -512,21 +529,21 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
                     const double2 z = make_double2(0.0, 0.0);
                     const double2 A2 = spec_apply<OP>(A, p.H[hi], needY ? p.Y[hi] : z, needD ? p.D1[hi] : z,
                                                       needD ? p.D2[hi] : z, mu, 1.0, acc);
-                    const double2 B2 = spec_apply<OP>(B, p.H[hi + n1], needY ? p.Y[hi + n1] : z,
-                                                      needD ? p.D1[hi + n1] : z, needD ? p.D2[hi + n1] : z, mu, 1.0,
+                    const double2 B2 = spec_apply<OP>(B, p.H[hin], needY ? p.Y[hin] : z,
+                                                      needD ? p.D1[hin] : z, needD ? p.D2[hin] : z, mu, 1.0,
                                                       acc);
                     v[s] = make_double2(A2.x - B2.y, A2.y + B2.x);             // A' + i B'
                 } else {
                     const double2 z = make_double2(0.0, 0.0);
-                    v[s] = spec_apply<OP>(v[s], p.H[hi + k], needY ? p.Y[hi + k] : z, needD ? p.D1[hi + k] : z,
-                                          needD ? p.D2[hi + k] : z, mu, 2.0, acc);
+                    v[s] = spec_apply<OP>(v[s], p.H[hik], needY ? p.Y[hik] : z, needD ? p.D1[hik] : z,
+                                          needD ? p.D2[hik] : z, mu, 2.0, acc);
                 }
             }
         } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int l = t + s * T;
-                const size_t hi = hbase + (size_t)l * (n1 + 1) + k;
+                const size_t hi = hbase + uidx(k, l);
                 const double2 z = make_double2(0.0, 0.0);
                 v[s] = spec_apply<OP>(v[s], p.H[hi], needY ? p.Y[hi] : z, needD ? p.D1[hi] : z,
                                       needD ? p.D2[hi] : z, mu, 2.0, acc);
@@ -570,7 +587,7 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     if (p.Sout) {
         double2 *__restrict__ out = p.Sout + ibase;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) out[(size_t)(t + s * T) * n1 + k] = v[s];
+        for (int s = 0; s < 8; ++s) out[sidx(t + s * T)] = v[s];
     }
 }
 
@@ -645,16 +662,64 @@ __global__ __launch_bounds__(64) void psf_spectrum_kernel(const double *__restri
     }
 }
 
+#include "fft_wave.inc"
+#include "fft_any.inc"
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// Sizes that take the wave-granular kernels and the tiled spectrum layout: one wave per column needs M/2 = 64 x 8 or
+// 64 x 16 points, the radix-16 row pass N = 1024 or 2048.  SBTV_FFT_WAVE=0 forces the workgroup kernels (A/B runs).
+static inline bool wave_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_FFT_WAVE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// row pass of the tiled sizes: the wave-granular kernel (SBTV_ROWS_KERNEL=wave) or the workgroup kernel (default: in
+// the solver loops, where H / Y come from HBM, it is the faster one - profiles/r02_fft_insitu.md)
+static inline bool rows_wave() {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_ROWS_KERNEL");
+        return e && e[0] == 'w' && e[1] == 'a';
+    }();
+    return on;
+}
+static inline int rows_v(int dflt) {     // values per thread of the wave-granular row pass (tuning hook: SBTV_ROWS_V=8|16)
+    static const int v = [] {
+        const char *e = getenv("SBTV_ROWS_V");
+        return e ? atoi(e) : 0;
+    }();
+    return (v == 8 || v == 16) ? v : dflt;
+}
+
 int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
-    if (!is_pow2(M) || !is_pow2(N) || M < 16 || N < 16 || M > 4096 || N > 4096)
-        return fail(ctx, SBTV_ERR_SIZE, "blur operator: M and N must be powers of two, 16 <= M, N <= 4096");
+    if (M < 2 || N < 2 || M > 4096 || N > 4096)
+        return fail(ctx, SBTV_ERR_SIZE, "blur operator: 2 <= M, N <= 4096");
     pl->M = M;
     pl->N = N;
     pl->batch = batch;
+    if (!is_pow2(M) || !is_pow2(N) || M < 16 || N < 16) {
+        // arbitrary size (utils/resize.m pads the kernel to ANY image size): chirp-z path, full complex spectra
+        pl->generic = 1;
+        pl->wave = 0;
+        pl->n1 = M;                       // so that 1 / (n1 N) is the inverse scale and S has n1 x N entries
+        pl->u_ld = 0;
+        pl->s_img = pl->u_img = (size_t)M * N;
+        pl->tw_n1 = nullptr;
+        SBTV_TRY(twiddle_get(ctx, M, &pl->tw_M));
+        SBTV_TRY(twiddle_get(ctx, N, &pl->tw_N));
+        return 0;
+    }
+    pl->generic = 0;
     pl->n1 = M / 2;
+    pl->s_img = (size_t)pl->n1 * N;
+    pl->wave = (wave_enabled() && (M == 1024 || M == 2048) && (N == 1024 || N == 2048)) ? 1 : 0;
+    // operator spectra: row-major U[k][l] with a padded leading dimension for the wave-granular row kernel, the
+    // column-major U[l][k] (leading dimension M/2 + 1, u_ld = 0) otherwise
+    pl->u_ld = (pl->wave && rows_wave()) ? N + 16 : 0;
+    pl->u_img = pl->u_ld ? (size_t)(pl->n1 + 1) * pl->u_ld : (size_t)(pl->n1 + 1) * N;
     SBTV_TRY(twiddle_get(ctx, pl->n1, &pl->tw_n1));
     SBTV_TRY(twiddle_get(ctx, M, &pl->tw_M));
     SBTV_TRY(twiddle_get(ctx, N, &pl->tw_N));
@@ -713,6 +778,18 @@ static void launch_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2
 
 int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S,
                    const int *frozen) {
+    if (pl.generic) return any_cols_fwd(ctx, pl, x, add, S, frozen);
+    if (pl.wave) {
+        const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
+        if (pl.n1 == 1024)
+            hipLaunchKernelGGL((cols_fwd_wave_kernel<10, 16>), grid, block, 0, ctx->stream, x, add, S, pl.tw_n1, pl.tw_M,
+                               pl.N, frozen);
+        else
+            hipLaunchKernelGGL((cols_fwd_wave_kernel<9, 8>), grid, block, 0, ctx->stream, x, add, S, pl.tw_n1, pl.tw_M,
+                               pl.N, frozen);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     const int L = ilog2(pl.n1);
 #define CALL(LL) launch_cols_fwd<LL>(ctx, pl, x, add, S, frozen)
     SBTV_DISPATCH_LOG2(L, CALL)
@@ -725,6 +802,18 @@ int fft_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double
 }
 
 int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen) {
+    if (pl.generic) return any_cols_inv(ctx, pl, S, x, scale, frozen, nullptr);
+    if (pl.wave) {
+        const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
+        if (pl.n1 == 1024)
+            hipLaunchKernelGGL((cols_inv_wave_kernel<10, 16, 0>), grid, block, 0, ctx->stream, S, x, pl.tw_n1,
+                               pl.tw_M, pl.N, scale, frozen, ColsPost{});
+        else
+            hipLaunchKernelGGL((cols_inv_wave_kernel<9, 8, 0>), grid, block, 0, ctx->stream, S, x, pl.tw_n1, pl.tw_M,
+                               pl.N, scale, frozen, ColsPost{});
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     const int L = ilog2(pl.n1);
 #define CALL(LL) launch_cols_inv<LL>(ctx, pl, S, x, scale, frozen)
     SBTV_DISPATCH_LOG2(L, CALL)
@@ -735,9 +824,32 @@ int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x
 int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale) {
     return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
 }
-int fft_cols_blocks(const FftPlan &pl) { return pl.N / cols_nseq(pl); }
+int fft_cols_blocks(const FftPlan &pl) { return (pl.wave || pl.generic) ? pl.N : pl.N / cols_nseq(pl); }
 int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
                       const ColsPost &post) {
+    if (pl.generic) return any_cols_inv(ctx, pl, S, x, scale, frozen, &post);
+    if (pl.wave) {
+        const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
+        const int pm = 1 + (post.tru ? 2 : 0) + (post.xprev ? 4 : 0);
+#define SBTV_POST_CASE(PM_)                                                                                          \
+    case PM_:                                                                                                        \
+        if (pl.n1 == 1024)                                                                                           \
+            hipLaunchKernelGGL((cols_inv_wave_kernel<10, 16, PM_>), grid, block, 0, ctx->stream, S, x, pl.tw_n1,       \
+                               pl.tw_M, pl.N, scale, frozen, post);                                                  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((cols_inv_wave_kernel<9, 8, PM_>), grid, block, 0, ctx->stream, S, x, pl.tw_n1,         \
+                               pl.tw_M, pl.N, scale, frozen, post);                                                  \
+        break;
+        switch (pm) {
+            SBTV_POST_CASE(1)
+            SBTV_POST_CASE(3)
+            SBTV_POST_CASE(5)
+            SBTV_POST_CASE(7)
+        }
+#undef SBTV_POST_CASE
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     const int L = ilog2(pl.n1);
 #define CALL(LL) launch_cols_inv_post<LL>(ctx, pl, S, x, scale, frozen, post)
     SBTV_DISPATCH_LOG2(L, CALL)
@@ -762,23 +874,47 @@ static inline int rows_rk(const FftPlan &pl) {
     const int small = (N == 512) ? 1 : (N == 256) ? 2 : rk;
     return (pl.n1 / rk < 128) ? small : rk;
 }
-int fft_rows_blocks(const FftPlan &pl) { return pl.n1 / rows_rk(pl); }
+int fft_rows_blocks(const FftPlan &pl) {
+    if (pl.generic) return ANY_SPEC_BLOCKS;
+    if (pl.wave) return rows_wave() ? pl.n1 / 2 : pl.n1 / 4;
+    return pl.n1 / rows_rk(pl);
+}
 
-template <int L, int RK>
-static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
-    const dim3 grid(pl.n1 / RK, pl.batch), block(RK * ((1 << L) / 8));
+template <int L, int V>
+static void launch_rows_wave(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
+    const dim3 grid(pl.n1 / 2, pl.batch), block(2 * ((1 << L) / V));
     switch (p.op) {
-        case OP_NONE: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_NONE>), grid, block, 0, ctx->stream, p); break;
-        case OP_MUL_H: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_MUL_H>), grid, block, 0, ctx->stream, p); break;
-        case OP_MUL_HC: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_MUL_HC>), grid, block, 0, ctx->stream, p); break;
-        case OP_INVLS: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_INVLS>), grid, block, 0, ctx->stream, p); break;
-        case OP_SALSA: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_SALSA>), grid, block, 0, ctx->stream, p); break;
-        case OP_RESID: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_RESID>), grid, block, 0, ctx->stream, p); break;
-        case OP_GRAD: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_GRAD>), grid, block, 0, ctx->stream, p); break;
-        case OP_ATA: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_ATA>), grid, block, 0, ctx->stream, p); break;
-        case OP_GRADF: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_GRADF>), grid, block, 0, ctx->stream, p); break;
+        case OP_NONE: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_NONE>), grid, block, 0, ctx->stream, p); break;
+        case OP_MUL_H: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_MUL_H>), grid, block, 0, ctx->stream, p); break;
+        case OP_MUL_HC: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_MUL_HC>), grid, block, 0, ctx->stream, p); break;
+        case OP_INVLS: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_INVLS>), grid, block, 0, ctx->stream, p); break;
+        case OP_SALSA: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_SALSA>), grid, block, 0, ctx->stream, p); break;
+        case OP_RESID: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_RESID>), grid, block, 0, ctx->stream, p); break;
+        case OP_GRAD: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_GRAD>), grid, block, 0, ctx->stream, p); break;
+        case OP_ATA: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_ATA>), grid, block, 0, ctx->stream, p); break;
+        case OP_GRADF: hipLaunchKernelGGL((rows_wave_kernel<L, V, OP_GRADF>), grid, block, 0, ctx->stream, p); break;
         default: break;
     }
+}
+
+template <int L, int RK, bool TILED = false>
+static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
+    const dim3 grid(pl.n1 / RK, pl.batch), block(RK * ((1 << L) / 8));
+#define SBTV_ROWS_OP(OP_)                                                                                     \
+    case OP_: hipLaunchKernelGGL((fft_rows_kernel<L, RK, OP_, TILED>), grid, block, 0, ctx->stream, p); break;
+    switch (p.op) {
+        SBTV_ROWS_OP(OP_NONE)
+        SBTV_ROWS_OP(OP_MUL_H)
+        SBTV_ROWS_OP(OP_MUL_HC)
+        SBTV_ROWS_OP(OP_INVLS)
+        SBTV_ROWS_OP(OP_SALSA)
+        SBTV_ROWS_OP(OP_RESID)
+        SBTV_ROWS_OP(OP_GRAD)
+        SBTV_ROWS_OP(OP_ATA)
+        SBTV_ROWS_OP(OP_GRADF)
+        default: break;
+    }
+#undef SBTV_ROWS_OP
 }
 
 int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout, const RowsArgs &a) {
@@ -798,8 +934,31 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.inv = a.dir_inv;
     p.op = a.op;
     p.shared_spec = a.shared_spec;
+    p.u_img = pl.u_img;
+    p.u_ld = pl.u_ld;
+    if (pl.generic) return any_rows(ctx, pl, p, Sout);
     const int L = ilog2(pl.N);
     if (L > 12) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 4096");
+    if (pl.wave && !rows_wave()) {
+        // the workgroup row kernel on the tiled layout: 4 rows x 4 columns = 256 contiguous bytes per access
+        if (L == 11) launch_rows<11, 4, true>(ctx, pl, p);
+        else launch_rows<10, 4, true>(ctx, pl, p);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    if (pl.wave) {
+        // values per thread: 16 (radix-16 stages) at N = 2048, 8 at N = 1024 (measured: profiles/r02_fft_lab.md)
+        const int V = rows_v(L == 11 ? 16 : 8);
+        if (L == 11) {
+            if (V == 8) launch_rows_wave<11, 8>(ctx, pl, p);
+            else launch_rows_wave<11, 16>(ctx, pl, p);
+        } else {
+            if (V == 8) launch_rows_wave<10, 8>(ctx, pl, p);
+            else launch_rows_wave<10, 16>(ctx, pl, p);
+        }
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     if (pl.N >= 512) {
         switch (L) {
             case 9:
@@ -832,6 +991,16 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
 }
 
 int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U) {
+    if (pl.generic) {          // the spectrum is already full: same layout as the operator spectra
+        SBTV_HIP(ctx, hipMemcpyAsync(U, S, sizeof(double2) * pl.s_img * pl.batch, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    if (pl.wave) {
+        hipLaunchKernelGGL(spec_unpack_tiled_kernel, dim3((pl.N + 63) / 64, pl.n1 + 1, pl.batch), dim3(64), 0,
+                           ctx->stream, S, U, pl.n1, pl.N, pl.u_ld);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     const int thr = 64;
     hipLaunchKernelGGL(spec_unpack_kernel, dim3((pl.n1 + 1 + thr - 1) / thr, pl.N, pl.batch), dim3(thr), 0,
                        ctx->stream, S, U, pl.n1, pl.N);
@@ -842,9 +1011,21 @@ int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U) 
 int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U) {
     const int thr = 64;
     if (taille > PSF_TMAX) return fail(ctx, SBTV_ERR_PSF, "PSF larger than 15 x 15");
+    if (pl.generic) return any_psf_spectrum(ctx, pl, taps_dev, taille, U);
     const size_t elems = (size_t)(pl.n1 + 1) * pl.N * pl.batch;
     int lch = (int)(elems >> 19);                       // 512^2, 1024^2: 1;  2048^2: 4;  8 x 1024^2: 8
     lch = lch < 1 ? 1 : (lch > 16 ? 16 : lch);
+    if (pl.u_ld) {
+        const dim3 gridw((pl.N + thr - 1) / thr, (pl.n1 + 1 + lch - 1) / lch, pl.batch);
+        if (taille == 7)
+            hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<7>, gridw, dim3(thr), 0, ctx->stream, taps_dev, taille, U,
+                               pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+        else
+            hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<0>, gridw, dim3(thr), 0, ctx->stream, taps_dev, taille, U,
+                               pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     const dim3 grid((pl.n1 + 1 + thr - 1) / thr, (pl.N + lch - 1) / lch, pl.batch);
     if (taille == 7)
         hipLaunchKernelGGL(psf_spectrum_kernel<7>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
@@ -868,6 +1049,8 @@ int sbtv_rfft2_packed(sbtv_ctx *ctx, const double *in, double *out, int M, int N
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     FftPlan pl;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &pl));
+    if (pl.generic)
+        return fail(ctx, SBTV_ERR_SIZE, "rfft2_packed: the packed half-spectrum format exists for powers of two 16..4096 only");
     const size_t cnt = (size_t)M * N * batch;
     const double *ind = nullptr;
     double *outd = nullptr;
@@ -877,15 +1060,34 @@ int sbtv_rfft2_packed(sbtv_ctx *ctx, const double *in, double *out, int M, int N
     SBTV_TRY(ws_get_t(ctx, "fft.tmp", cnt / 2, &tmp));
     RowsArgs a{};
     a.op = OP_NONE;
+    // the documented packed format is the plain one ([l][k]); sizes on the wave-granular path keep the spectrum tiled
+    // internally and convert at this (debug / test) boundary
+    double2 *tmp2 = nullptr;
+    if (pl.wave) SBTV_TRY(ws_get_t(ctx, "fft.tmp2", cnt / 2, &tmp2));
+    auto relayout = [&](const double2 *src, double2 *dst, int to_tiled) -> int {
+        hipLaunchKernelGGL(s_relayout_kernel, dim3(1024, batch), dim3(256), 0, ctx->stream, src, dst, pl.n1, N, to_tiled);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    };
     if (!inverse) {
         SBTV_TRY(fft_cols_fwd(ctx, pl, ind, nullptr, tmp));
         a.dir_fwd = 1;
         a.dir_inv = 0;
-        SBTV_TRY(fft_rows(ctx, pl, tmp, reinterpret_cast<double2 *>(outd), a));
+        if (pl.wave) {
+            SBTV_TRY(fft_rows(ctx, pl, tmp, tmp2, a));
+            SBTV_TRY(relayout(tmp2, reinterpret_cast<double2 *>(outd), 0));
+        } else {
+            SBTV_TRY(fft_rows(ctx, pl, tmp, reinterpret_cast<double2 *>(outd), a));
+        }
     } else {
         a.dir_fwd = 0;
         a.dir_inv = 1;
-        SBTV_TRY(fft_rows(ctx, pl, reinterpret_cast<const double2 *>(ind), tmp, a));
+        if (pl.wave) {
+            SBTV_TRY(relayout(reinterpret_cast<const double2 *>(ind), tmp2, 1));
+            SBTV_TRY(fft_rows(ctx, pl, tmp2, tmp, a));
+        } else {
+            SBTV_TRY(fft_rows(ctx, pl, reinterpret_cast<const double2 *>(ind), tmp, a));
+        }
         SBTV_TRY(fft_cols_inv(ctx, pl, tmp, outd, 1.0 / ((double)pl.n1 * N)));
     }
     SBTV_TRY(stage_out_copy(ctx, out, outd, cnt, flags));
@@ -924,8 +1126,8 @@ int sbtv_A_wrapper(sbtv_ctx *ctx, const double *taps, int taille, const double *
         SBTV_HIP(ctx, hipMemcpyAsync(mu_d, mu, sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
     }
     double2 *Hs = nullptr, *S = nullptr;
-    SBTV_TRY(ws_get_t(ctx, "op.H", (size_t)batch * (pl.n1 + 1) * N, &Hs));
-    SBTV_TRY(ws_get_t(ctx, "op.S", cnt / 2, &S));
+    SBTV_TRY(ws_get_t(ctx, "op.H", (size_t)batch * pl.u_img, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "op.S", (size_t)batch * pl.s_img, &S));
     SBTV_TRY(psf_spectrum(ctx, pl, taps_d, taille, Hs));
     SBTV_TRY(fft_cols_fwd(ctx, pl, xd, nullptr, S));
     RowsArgs a{};
@@ -964,7 +1166,7 @@ int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int re
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     FftPlan pl;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &pl));
-    const size_t P = (size_t)M * N, cnt = P * batch, spec = (size_t)(pl.n1 + 1) * N * batch;
+    const size_t P = (size_t)M * N, cnt = P * batch, spec = pl.u_img * batch;
     double *u = nullptr, *bu = nullptr, *g = nullptr, *tru = nullptr, *x = nullptr, *mu_d = nullptr, *taps_d = nullptr;
     double2 *S = nullptr, *H = nullptr, *Y = nullptr, *D1 = nullptr, *D2 = nullptr;
     SBTV_TRY(ws_get_t(ctx, "diag.u", cnt, &u));
@@ -972,7 +1174,7 @@ int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int re
     SBTV_TRY(ws_get_t(ctx, "diag.g", cnt, &g));
     SBTV_TRY(ws_get_t(ctx, "diag.tru", cnt, &tru));
     SBTV_TRY(ws_get_t(ctx, "diag.x", cnt, &x));
-    SBTV_TRY(ws_get_t(ctx, "diag.S", cnt / 2, &S));
+    SBTV_TRY(ws_get_t(ctx, "diag.S", (size_t)batch * pl.s_img, &S));
     SBTV_TRY(ws_get_t(ctx, "diag.H", spec, &H));
     SBTV_TRY(ws_get_t(ctx, "diag.Y", spec, &Y));
     SBTV_TRY(ws_get_t(ctx, "diag.D1", spec, &D1));

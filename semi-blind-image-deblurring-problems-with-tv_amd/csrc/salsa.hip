@@ -136,9 +136,9 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     SBTV_TRY(ws_get_t(ctx, "salsa.bu", cnt, &bu));
     SBTV_TRY(ws_get_t(ctx, "salsa.g", cnt, &g));
     double2 *S = nullptr, *Hs = nullptr, *Ys = nullptr;
-    SBTV_TRY(ws_get_t(ctx, "salsa.S", cnt / 2, &S));
-    SBTV_TRY(ws_get_t(ctx, "salsa.H", (size_t)batch * (fp.n1 + 1) * N, &Hs));
-    SBTV_TRY(ws_get_t(ctx, "salsa.Y", (size_t)batch * (fp.n1 + 1) * N, &Ys));
+    SBTV_TRY(ws_get_t(ctx, "salsa.S", (size_t)batch * fp.s_img, &S));
+    SBTV_TRY(ws_get_t(ctx, "salsa.H", (size_t)batch * fp.u_img, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "salsa.Y", (size_t)batch * fp.u_img, &Ys));
     // small per-image parameter arrays: [taps | mu | thr]
     double *par = nullptr;
     const size_t npar = (size_t)batch * taille * taille + 2 * (size_t)batch;
@@ -348,7 +348,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // host side of outer iteration `outer`: traces + stopping rule (:444-482)
     auto process = [&](int outer) -> int {
         const int slot = outer & 1;
-        SBTV_HIP(ctx, hipEventSynchronize(ev_done[slot]));
+        SBTV_TRY(wait_event(ctx, ev_done[slot]));
         if (prox_timed[slot]) {
             float ms = 0.f;
             SBTV_HIP(ctx, hipEventElapsedTime(&ms, ev_p0[slot], ev_p1[slot]));

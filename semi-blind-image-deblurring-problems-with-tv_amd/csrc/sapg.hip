@@ -98,6 +98,8 @@ int sbtv_max_eigenval(sbtv_ctx *ctx, const double *taps, int taille, const doubl
     if (!taps || !x0 || !val_out) return fail(ctx, SBTV_ERR_BADARG, "max_eigenval: bad arguments");
     if (taille < 1 || taille > 15 || taille > M || taille > N) return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    if (((size_t)M * N) & 1)
+        return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
     FftPlan fp;
     SBTV_TRY(fft_plan(ctx, M, N, 1, &fp));
     const size_t P = (size_t)M * N;
@@ -108,8 +110,8 @@ int sbtv_max_eigenval(sbtv_ctx *ctx, const double *taps, int taille, const doubl
     SBTV_TRY(ws_get_t(ctx, "ev.x", P, &x));
     SBTV_TRY(ws_get_t(ctx, "ev.taps", (size_t)taille * taille, &taps_d));
     SBTV_TRY(ws_get_t(ctx, "ev.o4", 4, &o4));
-    SBTV_TRY(ws_get_t(ctx, "ev.S", P / 2, &S));
-    SBTV_TRY(ws_get_t(ctx, "ev.H", (size_t)(fp.n1 + 1) * N, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "ev.S", fp.s_img, &S));
+    SBTV_TRY(ws_get_t(ctx, "ev.H", fp.u_img, &Hs));
     SBTV_HIP(ctx, hipMemcpyAsync(taps_d, taps, sizeof(double) * taille * taille, hipMemcpyHostToDevice, ctx->stream));
     SBTV_HIP(ctx, hipMemcpyAsync(x, x0d, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
     SBTV_TRY(psf_spectrum(ctx, fp, taps_d, taille, Hs));
@@ -161,6 +163,8 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     if (prox_iters <= 0) return fail(ctx, SBTV_ERR_MAXITER, "fista_tv: prox_iters must be positive");
     if (taille < 1 || taille > 15 || taille > M || taille > N) return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    if (((size_t)M * N) & 1)
+        return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
     FftPlan fp;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
     ProxPlan pp;
@@ -176,9 +180,9 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_TRY(ws_get_t(ctx, "fista.grad", cnt, &grad));
     SBTV_TRY(stage_out_buf(ctx, "fista.xfinal", x_out, cnt, flags, &xfinal));
     double2 *S = nullptr, *Hs = nullptr, *Bs = nullptr;
-    SBTV_TRY(ws_get_t(ctx, "fista.S", cnt / 2, &S));
-    SBTV_TRY(ws_get_t(ctx, "fista.H", (size_t)batch * (fp.n1 + 1) * N, &Hs));
-    SBTV_TRY(ws_get_t(ctx, "fista.B", (size_t)batch * (fp.n1 + 1) * N, &Bs));
+    SBTV_TRY(ws_get_t(ctx, "fista.S", (size_t)batch * fp.s_img, &S));
+    SBTV_TRY(ws_get_t(ctx, "fista.H", (size_t)batch * fp.u_img, &Hs));
+    SBTV_TRY(ws_get_t(ctx, "fista.B", (size_t)batch * fp.u_img, &Bs));
     const size_t npar = (size_t)batch * taille * taille + 2 * (size_t)batch;
     double *par = nullptr;
     SBTV_TRY(ws_get_t(ctx, "fista.par", npar, &par));
@@ -355,11 +359,13 @@ int sbtv_myula(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const do
     if (chambolleit <= 0) return fail(ctx, SBTV_ERR_MAXITER, "myula: chambolleit must be positive");
     if (taille < 1 || taille > 15 || taille > M || taille > N) return fail(ctx, SBTV_ERR_PSF, "Mask does not fit inside array");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    if (((size_t)M * N) & 1)
+        return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
     FftPlan fp;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
     ProxPlan pp;
     SBTV_TRY(prox_plan(ctx, M, N, batch, &pp));
-    const size_t P = (size_t)M * N, cnt = P * batch, spec = (size_t)(fp.n1 + 1) * N;
+    const size_t P = (size_t)M * N, cnt = P * batch, spec = fp.u_img;
     const double *yd = nullptr;
     SBTV_TRY(stage_in(ctx, "myula.y", y, cnt, flags, &yd));
     const bool noise_host = noise && !(flags & SBTV_DEVICE_PTRS);
@@ -369,7 +375,7 @@ int sbtv_myula(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const do
     SBTV_TRY(ws_get_t(ctx, "myula.prox", cnt, &prox));
     SBTV_TRY(ws_get_t(ctx, "myula.grad", cnt, &grad));
     if (noise_host) SBTV_TRY(ws_get_t(ctx, "myula.Z", cnt, &Z));
-    SBTV_TRY(ws_get_t(ctx, "myula.S", cnt / 2, &S));
+    SBTV_TRY(ws_get_t(ctx, "myula.S", (size_t)batch * fp.s_img, &S));
     SBTV_TRY(ws_get_t(ctx, "myula.H", spec * batch, &Hs));
     SBTV_TRY(ws_get_t(ctx, "myula.Y", spec * batch, &Ys));
     SBTV_TRY(ws_get_t(ctx, "myula.acc", (size_t)batch * 3 * fft_rows_blocks(fp), &acc));
@@ -443,6 +449,8 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     const int npar = (op->kind == SBTV_PSF_LAPLACE) ? 1 : 2;
     const int shared = op->share_gradients ? 1 : 0;
     const int nspec = shared ? 1 : batch;              // spectra sets (H, D1, D2, Y)
+    if (((size_t)M * N) & 1)
+        return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
     FftPlan fp, fps;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
     SBTV_TRY(fft_plan(ctx, M, N, nspec, &fps));
@@ -466,13 +474,13 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     SBTV_TRY(ws_get_t(ctx, "sapg.grad", cnt, &grad));
     SBTV_TRY(ws_get_t(ctx, "sapg.Z", cnt, &Z));
     double2 *S = nullptr, *Hs = nullptr, *D1s = nullptr, *D2s = nullptr, *Ys = nullptr, *S1 = nullptr;
-    const size_t spec = (size_t)(fp.n1 + 1) * N;
-    SBTV_TRY(ws_get_t(ctx, "sapg.S", cnt / 2, &S));
+    const size_t spec = fp.u_img;
+    SBTV_TRY(ws_get_t(ctx, "sapg.S", (size_t)batch * fp.s_img, &S));
     SBTV_TRY(ws_get_t(ctx, "sapg.H", spec * nspec, &Hs));
     SBTV_TRY(ws_get_t(ctx, "sapg.D1", spec * nspec, &D1s));
     SBTV_TRY(ws_get_t(ctx, "sapg.D2", spec * nspec, &D2s));
     SBTV_TRY(ws_get_t(ctx, "sapg.Y", spec * nspec, &Ys));
-    SBTV_TRY(ws_get_t(ctx, "sapg.S1", (size_t)nspec * P / 2, &S1));
+    SBTV_TRY(ws_get_t(ctx, "sapg.S1", (size_t)nspec * fp.s_img, &S1));
     const size_t t2 = (size_t)taille * taille;
     double *par = nullptr;       // [taps | d0 | d1] per spectrum set, then lam[batch], sigma2[batch], noise step
     const size_t npar_all = 3 * t2 * nspec + 2 * (size_t)batch + 1;
@@ -569,7 +577,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     };
     auto fetch_scalars = [&]() -> int {
         SBTV_TRY(collect_scalars());
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SBTV_TRY(wait_stream(ctx));
         return 0;
     };
     size_t noise_step = 0;
@@ -669,7 +677,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         stage[2 * batch] = (double)noise_step;
         ++noise_step;
         SBTV_HIP(ctx, hipGraphLaunch(*exec, ctx->stream));
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SBTV_TRY(wait_stream(ctx));
         *replayed = true;
         return 0;
     };

@@ -57,6 +57,7 @@ struct sbtv_ctx {
     double timing[4] = {0, 0, 0, 0};
     std::map<std::string, sbtv::DevBuf> ws;   // named device workspaces (grow-only)
     std::map<int, double2 *> twiddles;         // n -> exp(-2 pi i k / n), k < n
+    std::map<int, double2 *> any_axes;         // n -> Bluestein tables of the arbitrary-size path (fft_any.inc)
     void *pinned = nullptr;                    // pinned host staging for scalar read-back
     size_t pinned_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -161,6 +162,10 @@ struct ProxArm {
     const int *frozen;          // optional per-image flag: armed as done (FISTA batches)
 };
 
+// low-latency host waits of the solver loops (poll, then block; ctx.hip)
+int wait_event(sbtv_ctx *ctx, hipEvent_t ev);
+int wait_stream(sbtv_ctx *ctx);
+
 // hipGraph replay of launch-bound iteration bodies (ctx.hip)
 bool graph_wanted(size_t total_px);
 int graph_begin(sbtv_ctx *ctx);
@@ -214,6 +219,12 @@ enum SpecOp {
 struct FftPlan {
     int M, N, batch;
     int n1;                 // M/2  (column transform length, complex)
+    int wave;               // 1: wave-granular kernels + tiled spectrum layout (fft_wave.inc), chosen by the image size
+    int u_ld;               // wave mode: leading dimension of the row-major operator spectra U[k][l] (N + pad: a
+                            // power-of-two row stride would put every workgroup's row on the same memory channels)
+    size_t u_img;           // complex elements of ONE operator spectrum (H, Y, D1, D2) per image
+    size_t s_img;           // complex elements of the spectrum S of one image (M/2 x N packed; M x N in generic mode)
+    int generic;            // 1: arbitrary-size path (fft_any.inc): full complex spectra, n1 = M
     const double2 *tw_n1;   // twiddles of length n1
     const double2 *tw_M;    // twiddles of length M (split step)
     const double2 *tw_N;    // twiddles of length N

@@ -541,7 +541,7 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
         std::call_once(env_once, [] {
             if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,nw,minw[,rows_per_lane]"
                 int cj = 0, nw = 0, mw = 0, rpl = 2;
-                static const int known[][4] = {{8, 4, 2, 2}, {8, 8, 2, 2}, {8, 8, 1, 2}, {12, 4, 2, 2}, {16, 4, 1, 2},
+                static const int known[][4] = {{8, 4, 2, 2}, {8, 8, 2, 2}, {8, 8, 1, 2}, {8, 4, 3, 2}, {6, 8, 3, 2}, {12, 4, 2, 2}, {16, 4, 1, 2},
                                                {4, 8, 2, 2}, {4, 16, 2, 2}, {8, 6, 2, 2}, {4, 8, 3, 2}, {4, 8, 4, 2},
                                                {6, 8, 4, 2}, {6, 8, 2, 2}, {5, 8, 4, 2},
                                                {4, 8, 6, 1}, {4, 8, 5, 1}, {4, 8, 4, 1}, {8, 4, 6, 1}, {8, 8, 4, 1},
@@ -662,6 +662,8 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED_CASE(8, 4, 2)
             SBTV_FUSED_CASE(8, 8, 2)
             SBTV_FUSED_CASE(8, 8, 1)
+            SBTV_FUSED_CASE(8, 4, 3)
+            SBTV_FUSED_CASE(6, 8, 3)
             SBTV_FUSED_CASE(12, 4, 2)
             SBTV_FUSED_CASE(16, 4, 1)
             SBTV_FUSED_CASE(4, 8, 2)

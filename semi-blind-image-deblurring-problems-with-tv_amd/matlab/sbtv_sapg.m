@@ -3,11 +3,19 @@ function [eb, results] = sbtv_sapg(kind, y, op, c)
 %
 % kind: 0 gaussian (w1,w2), 1 moffat (alpha,beta), 2 laplace (b).  op / c are the reference's structs
 % (run_Gaussian_demo.m:34-39,186-204 and twins).  The likelihood closures op.f, op.gradF, op.grad_*,
-% op.proxG, op.logPi are NOT called: the library evaluates the same expressions spectrally on the GPU from
-% y, the PSF family and the current parameters (SURVEY.md §8 a-5).  MATLAB's randn stream is replaced by the
-% device Philox generator seeded with op.seed (default 1).
-persistent ctx
+% op.proxG, op.logPi are NOT called: the library evaluates the demos' stock expressions spectrally on the GPU
+% from y, the PSF family and the current parameters (SURVEY.md §8 a-5).  The shim cannot verify that the
+% handles in `op` ARE the stock closures, so it says so once per session (warning sbtv:closuresIgnored).
+% MATLAB's randn stream is replaced by the device Philox generator seeded with op.seed (default 1).
+% WRITTEN WITHOUT ACCESS TO MATLAB: never executed, see INTEGRATION.md.
+persistent ctx warned
 if isempty(ctx), ctx = sbtv_load(0); end
+if isempty(warned) && any(isfield(op, {'gradF','proxG','logPi','f','g'}))
+    warning('sbtv:closuresIgnored', ['op.gradF / op.proxG / op.logPi (and op.f, op.g, op.grad_*) are not called: the GPU path ' ...
+            'evaluates the stock closures of run_*_demo.m (Gaussian likelihood, TV prior with chambolleit = %d). ' ...
+            'A changed likelihood or prior is NOT picked up.'], getf(op,'chambolleit',25));
+    warned = true;
+end
 names = {{'w1','w2'}, {'alpha','beta'}, {'b'}};
 nm = names{kind+1};
 [M, N] = size(y);
@@ -44,12 +52,15 @@ results.execTimeFindParameters = toc;                       % fields of SAPG_alg
 results.last_samp = S;
 results.logPiTraceX = plp.Value; results.gXTrace = pgx.Value; results.logPiTrace_WU = pwu.Value(1:double(o.warmup));
 results.theta_EB = eb(1); results.thetas = pth.Value; results.last_theta = results.thetas(end);
+[results.mean_thetas, results.tol_thetas] = running_mean_tol(results.thetas, double(o.burnIn));
 ps = reshape(pps.Value, S, 2); gr = reshape(pgr.Value, S, 4);
 for q = 1:numel(nm)
     results.([nm{q} '_EB']) = eb(1+q); results.([nm{q} 's']) = ps(:,q)'; results.(['last_' nm{q}]) = ps(end,q);
     results.(['grad_' nm{q}]) = gr(:,1+q)'; results.(['c_' nm{q}]) = c.(nm{q});
+    [results.(['mean_' nm{q} 's']), results.(['tol_' nm{q} 's'])] = running_mean_tol(ps(:,q)', double(o.burnIn));
 end
 results.sigma_EB = eb(4); results.sigmas = psg.Value; results.last_sigma = results.sigmas(end);
+[results.mean_sigmas, results.tol_sigma] = running_mean_tol(results.sigmas, double(o.burnIn));
 results.grad_theta = gr(:,1)'; results.grad_sigma = gr(:,4)';
 results.c_theta = c.theta; results.c_sigma = c.sigma;
 perr = libpointer('doublePtr', zeros(1,S));                 % results.err_psf (l2 with the matrix 2-norm, utils/l2.m)
@@ -58,6 +69,18 @@ if rc ~= 0, error('sbtv:SAPG', '%s', calllib('libsbtv', 'sbtv_last_error', []));
 results.err_psf = perr.Value;
 results.Xlast_sample = reshape(pxl.Value, M, N);
 results.options = op;
+end
+
+function [m, tol] = running_mean_tol(tr, burnIn)
+% the running logs of SAPG_algorithm_Guassian.m:217-247: tol(ii) = |mean(tr(burnIn:ii)) - mean(tr(burnIn:ii-1))| /
+% mean(tr(burnIn:ii-1)) for ii >= 2 (NaN while the window burnIn:ii-1 is empty, 0 at ii = 1), and
+% m(ii - burnIn) = mean(tr(burnIn:ii)) for ii > burnIn
+S = numel(tr);
+tol = zeros(1, S); m = zeros(1, max(S - burnIn, 0));
+for ii = 2:S
+    tol(ii) = abs(mean(tr(burnIn:ii)) - mean(tr(burnIn:ii-1))) / mean(tr(burnIn:ii-1));
+    if ii > burnIn, m(ii - burnIn) = mean(tr(burnIn:ii)); end
+end
 end
 
 function v = getf(s, name, default)

@@ -104,6 +104,61 @@ class BlurOperator:
 
     __call__ = A
 
+    @classmethod
+    def from_handle(cls, A, shape, like=None, ctx=None, max_taille=15, rtol=1e-10):
+        """Recover the PSF taps from a plain function handle of the blur: the reference builds A as
+        real(ifft2(resize(h) .* fft2(x))) with the kernel zero-padded into the TOP-LEFT corner (utils/resize.m:8-11,
+        quirk Q6), so A(delta) IS the padded kernel.  One probe call; the response must be confined (to `rtol` of its
+        largest entry) to a top-left square of at most 15 x 15, otherwise the handle is not a compact circular blur
+        and cannot run on the GPU path.  `like`: an image of the caller (numpy array or CUDA tensor) whose kind the
+        probe takes."""
+        M, N = int(shape[0]), int(shape[1])
+        d = np.zeros((M, N))
+        d[0, 0] = 1.0
+        if like is not None and L._is_torch(like):
+            r = L.to_host(A(L.to_device(d, like.device)))
+        else:
+            r = np.asarray(A(d), dtype=np.float64)
+        if r.shape != (M, N):
+            raise L.SbtvError(-10, "A(delta) has the wrong size: the handle is not an image-to-image blur")
+        big = float(np.max(np.abs(r)))
+        sig = np.abs(r) > rtol * big
+        rows, cols = np.nonzero(sig)
+        t = int(max(rows.max(), cols.max())) + 1 if rows.size else 1
+        if t > max_taille or t > M or t > N:
+            raise L.SbtvError(-10, "A(delta) is not confined to a top-left square of at most 15 x 15: the handle is "
+                                   "not a compact circular blur built by utils/resize.m (Mask does not fit)")
+        return cls(r[:t, :t].copy(), ctx=ctx)
+
+    def mu_of_handle(self, LS, shape, like=None, rtol=1e-8):
+        """The mu a plain invLS handle was built with (run_Gaussian_demo.m:222-225: filter = 1./(abs(H).^2 + mu)):
+        the sum of invLS(delta) is the DC gain 1 / (H(0,0)^2 + mu) with H(0,0) = sum of the taps.  The whole response is
+        then checked against this operator's own invLS (on the GPU) so that an unrelated handle is refused."""
+        M, N = int(shape[0]), int(shape[1])
+        d = np.zeros((M, N))
+        d[0, 0] = 1.0
+        tor = like is not None and L._is_torch(like)
+        r = L.to_host(LS(L.to_device(d, like.device))) if tor else np.asarray(LS(d), dtype=np.float64)
+        h00 = float(np.sum(self.taps[0]))
+        mu = 1.0 / float(np.sum(r)) - h00 * h00
+        if not (mu > 0):
+            raise L.SbtvError(-9, "(A^T A + \\mu I)^(-1): the LS handle does not have the form 1./(abs(H).^2 + mu)")
+        mine = np.asarray(self.invLS(d, mu), dtype=np.float64)
+        if np.max(np.abs(mine - r)) > rtol * np.max(np.abs(r)):
+            raise L.SbtvError(-9, "(A^T A + \\mu I)^(-1): the LS handle is not the inverse filter of A")
+        return mu
+
+    def check_adjoint_handle(self, AT, shape, like=None, rtol=1e-8):
+        """A plain AT handle must be the adjoint of this blur (AT(delta) == this operator's AT(delta))."""
+        M, N = int(shape[0]), int(shape[1])
+        d = np.zeros((M, N))
+        d[0, 0] = 1.0
+        tor = like is not None and L._is_torch(like)
+        r = L.to_host(AT(L.to_device(d, like.device))) if tor else np.asarray(AT(d), dtype=np.float64)
+        mine = np.asarray(self.AT(d), dtype=np.float64)
+        if r.shape != mine.shape or np.max(np.abs(mine - r)) > rtol * np.max(np.abs(mine)):
+            raise L.SbtvError(-8, "The function handle for transpose of A is not the adjoint of A")
+
     @property
     def T(self):
         return _Adjoint(self)

@@ -21,9 +21,14 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
     'MU', 'AT', 'LS', 'STOPCRITERION', 'TOLERANCEA', 'MAXITERA', 'TRUE_X',
     'INITIALIZATION', 'TVINITIALIZATION', 'TVITERS', 'PSI', 'PHI', 'VERBOSE', 'P', 'PT'.
 
-    `A` must be a sbtv.BlurOperator (the FFT closure over PSF taps), 'AT' its
-    `.T` and 'LS' its `.LS(mu)`: arbitrary Python callables cannot run on the
-    GPU.  Only the TV path ('TVINITIALIZATION' = 1) is implemented; as in the
+    `A` is a sbtv.BlurOperator (the FFT closure over PSF taps) with 'AT' its `.T` and 'LS' its `.LS(mu)` - or, as in
+    run_Gaussian_demo.m:229-242, three plain function handles: the taps are then recovered by probing A(delta)
+    (the reference pads the kernel into the top-left corner, utils/resize.m:8-11), mu by probing LS(delta), and
+    'AT' / 'LS' are checked against the recovered operator (three probe calls; the handles themselves are never
+    called inside the GPU loop, so a handle that is NOT a compact circular blur is refused, not emulated).
+    'MU' must be the mu the 'LS' filter was built with: the C-ABI has one mu (the reference's demos pass the same
+    value to both, run_Gaussian_demo.m:219-225); a mismatch raises instead of silently preferring one.
+    Only the TV path ('TVINITIALIZATION' = 1) is implemented; as in the
     reference a user 'PSI'/'PHI' is then ignored with a warning (quirk Q7,
     SALSA_v2.m:318-320).  y may be (M,N), a batch (B,M,N) (tau, 'MU' and the
     PSF may then be per image) or a column-major CUDA tensor.
@@ -32,17 +37,30 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
     for k, v in kw.items():
         opts[k.upper()] = v
     ctx = ctx or L.default_context()
-    if not isinstance(A, BlurOperator):
-        raise TypeError("A must be a sbtv.BlurOperator (matrix / generic handle A is not supported on the GPU path)")
     AT = opts.get("AT", 0)
+    LS = opts.get("LS", None)
+    mu = opts.get("MU", 1e-3)                                                                 # :176
+    if not isinstance(A, BlurOperator):
+        if not callable(A):
+            raise TypeError("A must be a sbtv.BlurOperator or a function handle (a matrix A is not supported)")
+        if not callable(AT):
+            raise L.SbtvError(-8, "The function handle for transpose of A is missing")       # SALSA_v2.m:262
+        if not callable(LS):
+            raise L.SbtvError(-9, "(A^T A + \\mu I)^(-1) must be specified as a function handle.")  # :296
+        shape = tuple(y.shape[-2:])
+        like = y if L._is_torch(y) else None
+        A = BlurOperator.from_handle(A, shape, like=like, ctx=ctx)
+        A.check_adjoint_handle(AT, shape, like=like)
+        AT, LS = A.T, A.LS(A.mu_of_handle(LS, shape, like=like))
     if not isinstance(AT, _Adjoint) or AT.op is not A:
         raise L.SbtvError(-8, "The function handle for transpose of A is missing")           # SALSA_v2.m:262
-    mu = opts.get("MU", 1e-3)                                                                 # :176
-    LS = opts.get("LS", None)
     if not isinstance(LS, _InvLS) or LS.op is not A:
         raise L.SbtvError(-9, "(A^T A + \\mu I)^(-1) must be specified as a function handle.")  # :296
     if "MU" not in opts:
         mu = LS.mu
+    elif not np.allclose(np.asarray(mu, dtype=np.float64), np.asarray(LS.mu, dtype=np.float64), rtol=1e-6, atol=0.0):
+        raise L.SbtvError(-9, "'MU' differs from the mu the 'LS' filter was built with: the GPU path has one mu "
+                              "(run_Gaussian_demo.m:219-225 passes the same value to both)")
     if ("P" in opts) != ("PT" in opts):
         raise ValueError("If you give P you must also give PT, and vice versa.")               # :252
     if "P" in opts:

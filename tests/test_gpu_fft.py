@@ -73,7 +73,10 @@ def test_operator_errors(ctx):
     import sbtv
     op = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
     with pytest.raises(sbtv.SbtvError) as e:
-        op.A(np.zeros((48, 48)))                    # not a power of two
+        op.A(np.zeros((4100, 48)))                  # larger than 4096 (any other size runs: tests/test_gpu_anysize.py)
+    assert e.value.code == -2
+    with pytest.raises(sbtv.SbtvError) as e:
+        sbtv.rfft2_packed(np.zeros((48, 48)))       # the packed half-spectrum format is a power-of-two format
     assert e.value.code == -2
     with pytest.raises(sbtv.SbtvError) as e:
         op.apply(np.zeros((32, 32)), 4)             # A_wrapper.m:15

@@ -243,3 +243,47 @@ def test_salsa_random_initialization(ctx):
     assert len(got[3]) == len(ref["objective"])
     np.testing.assert_allclose(got[3], ref["objective"], rtol=1e-9)
     assert np.max(np.abs(got[0] - ref["x"])) < 1e-6
+
+
+def test_salsa_takes_the_demos_plain_function_handles(ctx, cman256):
+    """run_Gaussian_demo.m:215-242 passes three FFT closures (A1, AT1, invLS) and 'MU': the mirror recovers the PSF by
+    probing A(delta) (the kernel sits in the top-left corner, utils/resize.m:8-11, quirk Q6) and mu by probing
+    invLS(delta), checks AT / LS against the recovered operator, and then runs the same GPU solve as with a
+    sbtv.BlurOperator.  Handles that are not a compact circular blur, an AT that is not the adjoint, or a 'MU' that
+    differs from the LS filter's mu are refused."""
+    import sbtv
+    import sbtv_oracle as o
+    x = cman256
+    st = o.demo_setup("gaussian", x, np.random.default_rng(3).standard_normal(x.shape), evMax=1.0)
+    taps = o.Gaussian_psf(7, 0.4, 0.3)
+    H = o.resize(taps, x.shape)
+    mu = 0.003
+    A = lambda v: np.real(np.fft.ifft2(H * np.fft.fft2(v)))                      # run_Gaussian_demo.m:136
+    AT = lambda v: np.real(np.fft.ifft2(np.conj(H) * np.fft.fft2(v)))            # :137
+    invLS = lambda v: np.real(np.fft.ifft2(np.fft.fft2(v) / (np.abs(H) ** 2 + mu)))   # :224-225
+    tau = 0.03 * st["sigma"] ** 2
+    args = ("StopCriterion", 1, "True_x", x, "ToleranceA", 1e-5, "MAXITERA", 60, "TVINITIALIZATION", 1, "TViters", 10,
+            "VERBOSE", 0)
+    got = sbtv.SALSA_v2(st["y"], A, tau, "MU", mu, "AT", AT, "LS", invLS, *args)
+    op = sbtv.BlurOperator(taps)
+    want = sbtv.SALSA_v2(st["y"], op, tau, "MU", mu, "AT", op.T, "LS", op.LS(mu), *args)
+    assert len(got[3]) == len(want[3])
+    np.testing.assert_allclose(got[3], want[3], rtol=1e-9)          # taps recovered through an FFT round trip: ~1e-16
+    assert np.max(np.abs(got[0] - want[0])) < 1e-7
+    rec = sbtv.BlurOperator.from_handle(A, x.shape)
+    assert rec.taille == 7 and np.max(np.abs(rec.taps[0] - taps)) < 1e-15
+    assert rec.mu_of_handle(invLS, x.shape) == pytest.approx(mu, rel=1e-9)
+    with pytest.raises(sbtv.SbtvError) as e:                          # 'MU' is not the LS filter's mu
+        sbtv.SALSA_v2(st["y"], A, tau, "MU", 2 * mu, "AT", AT, "LS", invLS, *args)
+    assert e.value.code == -9
+    with pytest.raises(sbtv.SbtvError) as e:                          # AT is not the adjoint
+        sbtv.SALSA_v2(st["y"], A, tau, "MU", mu, "AT", A, "LS", invLS, *args)
+    assert e.value.code == -8
+    wide = np.zeros(x.shape); wide[:21, :21] = 1.0 / 441
+    Hw = np.fft.fft2(wide)
+    with pytest.raises(sbtv.SbtvError) as e:                          # a 21 x 21 box blur is not a <= 15 x 15 PSF
+        sbtv.SALSA_v2(st["y"], lambda v: np.real(np.fft.ifft2(Hw * np.fft.fft2(v))), tau, "MU", mu, "AT", AT, "LS",
+                      invLS, *args)
+    assert e.value.code == -10
+    with pytest.raises(sbtv.SbtvError):                               # handles missing altogether (SALSA_v2.m:262,296)
+        sbtv.SALSA_v2(st["y"], A, tau, "MU", mu, "LS", invLS, *args)

@@ -461,7 +461,7 @@ def test_sapg_shared_gradient_chains_match_oracle(ctx):
     M = N = 32
     x = synth_image(M, N, 3)
     rng = np.random.default_rng(2)
-    for kind, p_init in (("gaussian", (0.5, 0.35)), ("moffat", None)):
+    for kind, p_init in (("gaussian", (0.5, 0.35)), ("moffat", (0.6, 5.0))):
         st = o.demo_setup(kind, x, rng.standard_normal((M, N)), evMax=0.99)
         C_, samples, warmup, burnIn = 2, 7, 4, 4
         nz = rng.standard_normal((warmup - 1 + samples - 1, C_, M, N))      # [step][chain]
