@@ -150,29 +150,33 @@ def pass_block(ctx, size, names, reps):
     return out
 
 
-def chambolle_roofline(tm, size, pmc, pmc_state):
+def chambolle_roofline(tm, size, pmc, pmc_state, kind="tile"):
     """Roofline entries of the fused Chambolle kernel from the live event bracket of the timed solve."""
     P = float(size * size)
     iters = tm["chambolle_launches"]                      # Chambolle iterations actually run
-    launches = max(iters / FUSED_STEPS, 1.0)
+    fused = 10 if kind == "pipeline" else FUSED_STEPS
+    kname = "chambolle_pipe_kernel" if kind == "pipeline" else "chambolle_fused_kernel"
+    launches = max(iters / fused, 1.0)
     avg_s = tm["chambolle_ms"] * 1e-3 / launches           # bracket incl. the ~5 us control kernels (pessimistic)
     # minimum traffic of the temporally fused design: every launch reads g, px, py and writes px, py once over the
-    # image; the second launch of a prox also writes f: (40 + 48) / 2 B per pixel and launch
-    model_bytes = 44.0 * P
+    # image; the last launch of a prox also writes f: (40 + 48) / 2 B per pixel and launch with two launches per prox,
+    # 48 with one (pipeline kernel)
+    model_bytes = (48.0 if kind == "pipeline" else 44.0) * P
     hbm = {"bound": "hbm", "achieved": model_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "model_bytes_per_launch": model_bytes,
-           "model": "fused design: read g,px,py + write px,py once per 5-iteration launch (+ f on every second one)"}
+           "model": "fused design: read g,px,py + write px,py once per %d-iteration launch (+ f on the last launch of a "
+                    "prox)" % fused}
     hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
-    per_it_bytes = 40.0 * P * FUSED_STEPS
-    common = {"kernel": "chambolle_fused_kernel<4,8,4> (5 Chambolle iterations per launch)", "avg_launch_ms": avg_s * 1e3,
-              "launches": launches, "iterations_per_launch": FUSED_STEPS,
+    per_it_bytes = 40.0 * P * fused
+    common = {"kernel": "%s (%d Chambolle iterations per launch)" % (kname, fused), "avg_launch_ms": avg_s * 1e3,
+              "launches": launches, "iterations_per_launch": fused,
               "us_per_chambolle_iteration": 1e3 * tm["chambolle_ms"] / max(iters, 1),
               # the unfused byte count of SURVEY.md §8d for reference only: 5 iterations x 40 B/px share one pass over
               # memory, so this is NOT a bound for the fused kernel (it exceeds the HBM peak)
               "unfused_algorithmic_gbs": per_it_bytes / avg_s / 1e9, "pmc_file": pmc_state}
     k = None
     if pmc:
-        k = next((v for n, v in pmc.get("kernels", {}).items() if n.startswith("chambolle_fused_kernel")), None)
+        k = next((v for n, v in pmc.get("kernels", {}).items() if n.startswith(kname)), None)
     if k and k.get("valu_insts_per_launch"):
         traffic = k.get("hbm_bytes_per_launch")
         hbm["traffic"] = traffic
@@ -183,7 +187,7 @@ def chambolle_roofline(tm, size, pmc, pmc_state):
                 "valu_wave_insts_per_launch": k["valu_insts_per_launch"],
                 # instructions spent on core pixels only (the halo of the temporal blocking is recomputed work)
                 "useful_frac": issued / VALU_F64_PEAK_TINSTR * k.get("core_fraction", 1.0),
-                "note": "fp64 vector issue is the bound that binds (5 iterations per pass over memory); achieved = "
+                "note": "fp64 vector issue is the bound that binds (several iterations per pass over memory); achieved = "
                         "VALU instructions of one launch (PMC, this source revision) x 64 lanes / live launch time",
                 "hbm": hbm}
     else:
@@ -323,7 +327,7 @@ def main():
                        "image": [SIZE, SIZE], "images_per_gpu": 1, "parallelism": f"images x{world}"},
             "final_psnr_db": final_psnr, "outer_iterations_to_tol_1e-5": n_conv,
             "loop_ms_per_step_device": tm["loop_ms"] / args.steps,
-            "roofline": chambolle_roofline(tm, SIZE, pmc, pmc_state),
+            "roofline": chambolle_roofline(tm, SIZE, pmc, pmc_state, ctx.prox_variant(SIZE, SIZE)["kind"]),
         }
         # step level: bytes the whole outer iteration moves / measured step time
         model_step = model_step_bytes(SIZE)
@@ -345,15 +349,19 @@ def main():
             r5 = solve(500, 1e-5, y5d, x5d, tau5)
             k5 = max(4 * args.steps, 400)
             solve(50, -1.0, y5d, x5d, tau5)
-            torch.cuda.synchronize()
-            t5 = time.perf_counter()
-            solve(k5, -1.0, y5d, x5d, tau5)
-            torch.cuda.synchronize()
-            e5 = time.perf_counter() - t5
+            samples5 = []
+            for _ in range(3):       # launch-bound regime: the host's wake-up latency makes single runs noisy
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                solve(k5, -1.0, y5d, x5d, tau5)
+                torch.cuda.synchronize()
+                samples5.append(time.perf_counter() - t5)
+            e5 = min(samples5)
             tm5 = ctx.last_timing()
             line["extra_512"] = {
                 "workload": "the same SALSA_v2 solve on 512x512 man.png (BASELINE configs[1])", "image": [512, 512],
                 "value": k5 / e5, "unit": "SALSA outer-iterations/s", "steps": k5, "ms_per_step": 1e3 * e5 / k5,
+                "samples_it_per_s": [k5 / e for e in samples5], "value_is": "best of 3 timed runs",
                 "final_psnr_db": psnr(x5, sbtv.to_host(r5[0])), "outer_iterations_to_tol_1e-5": len(r5[3]) - 1,
                 "us_per_chambolle_iteration": 1e3 * tm5["chambolle_ms"] / max(tm5["chambolle_launches"], 1),
                 "step_roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",

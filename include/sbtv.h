@@ -306,8 +306,8 @@ int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N,
  *   them (SBTV_ERR_CANARY on damage).  This call verifies on demand: *enabled, number of guarded workspaces, damaged
  *   bytes.  poke = 1 first overwrites the rear guard of one workspace (self-test of the detector) and repairs it.
  * sbtv_diag_prox_variant: which TV-prox kernel a (M, N, batch) problem takes: out = {columns per wave, waves per
- *   workgroup, waves per SIMD requested, rows per lane, tiles per image, 1 = temporally fused kernel / 0 = the
- *   one-iteration kernels (odd M, SBTV_SINGLE_STEP)} — lets a parity test assert which kernel it exercised.
+ *   workgroup, waves per SIMD requested, rows per lane, tiles per image, 2 = streaming pipeline kernel / 1 = temporally
+ *   fused tile kernel / 0 = the one-iteration kernels (odd M, SBTV_SINGLE_STEP)} — lets a parity test assert which kernel it exercised.
  * sbtv_diag_time_pass: times ONE pass of the hot path on scratch data of the given shape with HIP events on the
  *   context stream (`reps` launches after two untimed ones) -> average ms per launch and the algorithmic bytes of one
  *   launch.  pass: 0 forward column FFT of u+bu; 1 row pass with the SALSA spectral solve (forward FFT, operator,

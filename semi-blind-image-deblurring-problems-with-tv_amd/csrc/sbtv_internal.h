@@ -177,6 +177,7 @@ struct ProxPlan {
     int tiles_i, tiles_j, nblk;   // blocks per image (one-iteration kernels)
     int ftiles_i, ftiles_j, fnblk; // blocks per image (temporally fused kernel)
     int cj, nw, minw, rpl;        // fused-kernel variant of this plan (columns per wave, waves, waves/SIMD, rows per lane)
+    int pipe, nbands, nseg, seglen;   // pipe = 1: streaming pipeline kernel (tv_pipe.inc): bands x column segments
     ProxCtrl *ctrl;               // [batch]
     double *pbuf;                 // [2 pingpong][2 (px,py)][batch][M*N]
     double *partials;             // [batch][nblk]

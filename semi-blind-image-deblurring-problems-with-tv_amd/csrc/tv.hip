@@ -218,7 +218,9 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
 // exactly that many steps from the untouched input buffer, so results are
 // identical to one-iteration-at-a-time execution.
 // ---------------------------------------------------------------------------
-constexpr int FH = 6;                    // halo = max fused iterations
+constexpr int FH = 6;                    // halo = max fused iterations of the TILE kernels
+constexpr int FSMAX = 10;                // most iterations ANY fused kernel runs per launch (pipeline kernel: 10):
+                                         // stride of the per-step error partials and size of the control arrays
 constexpr int FHJ = 5;                   // right column halo = max steps per launch (rows need an even halo: FH)
 constexpr int FHL = FHJ + 1;             // left column halo: one more, because f = g - lambda div p written by the
                                          // last launch needs py(i, j-1) of the FINAL iterate left of the core
@@ -309,7 +311,7 @@ __device__ __forceinline__ void fused_apply_stop_rule(ProxCtrl *c, const double 
 __device__ __forceinline__ void fused_inline_ctrl(ProxCtrl *__restrict__ c, const double *__restrict__ partials_b,
                                                   int nblk, int nsteps, int write_f,
                                                   unsigned *__restrict__ counter_b, int redo_mode) {
-    __shared__ double ic_tots[FH];
+    __shared__ double ic_tots[FSMAX];
     __shared__ int ic_last;
     // The partials were stored write-through (`sc1`, fused_store_partial) so no release fence (an L2
     // write-back of the megabytes of freshly written duals!) is needed: drain, barrier, ticket.
@@ -352,14 +354,15 @@ __device__ __forceinline__ void fused_inline_ctrl(ProxCtrl *__restrict__ c, cons
 
 #include "tv_fused.inc"
 #include "tv_fused1.inc"
+#include "tv_pipe.inc"
 
 // Stop rule after a fused launch of `steps_arg` iterations (see the kernel header).
-__global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
+__global__ __launch_bounds__(64 * FSMAX) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
                                                                        const double *__restrict__ partials, int nblk,
                                                                        int steps_arg, int redo_mode, int write_f) {
     const int b = blockIdx.x;
     ProxCtrl *c = &ctrl[b];
-    __shared__ double tots[FH];
+    __shared__ double tots[FSMAX];
     int nsteps;
     if (redo_mode) {
         if (c->redo <= 0) {
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(64 * FH) void chambolle_fused_ctrl_kernel(ProxCtrl 
         nsteps = min(steps_arg, c->maxiter - c->k);
         if (nsteps <= 0) return;
     }
-    fused_reduce_steps(partials + (size_t)b * FH * nblk, nblk, nsteps, tots);
+    fused_reduce_steps(partials + (size_t)b * FSMAX * nblk, nblk, nsteps, tots);
     if (threadIdx.x == 0) {
         if (redo_mode) {
             c->k += nsteps;
@@ -579,9 +582,35 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
         geometry(4, 8, 1);
         pl->minw = 4;
     }
+    // Streaming pipeline kernel (tv_pipe.inc): bands of PCI core rows x column segments, one workgroup per CU.
+    // OPT-IN (SBTV_PROX_PIPE=1, any even M): on MI355X it does 1.34 x instead of 1.68 x the arithmetic and a third of
+    // the memory traffic, but one barrier per column step with ~100 instructions of work per wave in between leaves
+    // the vector units idle half of the time: 21.1 vs 14.7 us per Chambolle iteration at 2048^2
+    // (profiles/r02_chambolle_variants.md).  Kept as the measured alternative, exercised by the parity suite.
+    pl->pipe = 0;
+    {
+        static const int env_pipe = [] {
+            const char *e = getenv("SBTV_PROX_PIPE");
+            return e ? atoi(e) : -1;
+        }();
+        const int nbands = (M + PCI - 1) / PCI;
+        int nseg = 256 / (nbands * batch);
+        if (nseg < 1) nseg = 1;
+        if (nseg > N / 80) nseg = N / 80;
+        if (nseg < 1) nseg = 1;
+        const int seglen = (N + nseg - 1) / nseg;
+        nseg = (N + seglen - 1) / seglen;
+        if (env_pipe == 1 && (M % 2 == 0) && !g_fused_forced) {
+            pl->pipe = 1;
+            pl->nbands = nbands;
+            pl->nseg = nseg;
+            pl->seglen = seglen;
+            pl->fnblk = nbands * nseg;
+        }
+    }
     const size_t P = (size_t)M * N;
     size_t npart = (size_t)batch * pl->nblk;
-    if ((size_t)batch * FH * pl->fnblk > npart) npart = (size_t)batch * FH * pl->fnblk;
+    if ((size_t)batch * FSMAX * pl->fnblk > npart) npart = (size_t)batch * FSMAX * pl->fnblk;
     const std::string t(tag ? tag : "prox");          // a second concurrent prox (CoRAL) needs its own state
     SBTV_TRY(ws_get_t(ctx, (t + ".ctrl").c_str(), (size_t)batch, &pl->ctrl));
     SBTV_TRY(ws_get_t(ctx, (t + ".pbuf").c_str(), 4 * P * batch, &pl->pbuf));
@@ -634,7 +663,8 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
     if (v && !env_single && !g_force_single_step && (!f_out || vec_ok(f_out, pl.M))) {
         // temporally fused path: ceil(K/FH) launches of (nearly) equal step counts + the redo pair
         const dim3 fgrid(pl.fnblk, 1, pl.batch);   // linear tile list, remapped per XCD inside the kernel
-        const int nl = (maxiter + FHJ - 1) / FHJ;
+        const int per_launch = pl.pipe ? PK : FHJ;
+        const int nl = (maxiter + per_launch - 1) / per_launch;
         const int base = maxiter / nl, extra = maxiter % nl;
         // In-kernel stop rule: the last workgroup of a normal launch applies the rule itself instead of a separate
         // control kernel.  On large grids the gain is marginal (+0.6 % SALSA it/s at 2048^2), so there it needs
@@ -647,8 +677,19 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             bool launched = false;
             const int inl = (!redo && env_inline) ? 1 : 0;
             const int kflags = inl | (cold ? 2 : 0);            // bit 0: in-kernel stop rule, bit 1: cold start
+            if (pl.pipe) {
+                launched = true;
+                if (g_fused.fast)
+                    hipLaunchKernelGGL(chambolle_pipe_kernel<true>, fgrid, dim3(64 * PNW), 0, ctx->stream, g, pl.pbuf,
+                                       pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.nbands, pl.nseg, pl.seglen, pl.fnblk,
+                                       steps, redo, f_out, write_f, pl.counters, kflags);
+                else
+                    hipLaunchKernelGGL(chambolle_pipe_kernel<false>, fgrid, dim3(64 * PNW), 0, ctx->stream, g, pl.pbuf,
+                                       pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.nbands, pl.nseg, pl.seglen, pl.fnblk,
+                                       steps, redo, f_out, write_f, pl.counters, kflags);
+            }
 #define SBTV_FUSED_CASE(CJ_, NW_, MW_)                                                                               \
-    if (pl.rpl == 2 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {                         \
+    if (!pl.pipe && pl.rpl == 2 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {             \
         launched = true;                                                                                             \
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
@@ -676,7 +717,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED_CASE(5, 8, 4)
 #undef SBTV_FUSED_CASE
 #define SBTV_FUSED1_CASE(CJ_, NW_, MW_)                                                                              \
-    if (pl.rpl == 1 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {                         \
+    if (!pl.pipe && pl.rpl == 1 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {             \
         launched = true;                                                                                             \
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused1_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0,             \
@@ -701,7 +742,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                 return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: no fused Chambolle kernel is compiled for this tile geometry");
             // the re-run launch books its own result (last-workgroup ticket; nothing at all when it is empty)
             if (!inl && !redo)
-                hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FH), 0, ctx->stream,
+                hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FSMAX), 0, ctx->stream,
                                    pl.ctrl, pl.partials, pl.fnblk, steps, redo, write_f);
             return 0;
         };
@@ -836,7 +877,7 @@ int sbtv_diag_prox_variant(sbtv_ctx *ctx, int M, int N, int batch, int out[6]) {
     out[2] = pl.minw;
     out[3] = pl.rpl;
     out[4] = pl.fnblk;
-    out[5] = (M % 2 == 0 && !env_single && !g_force_single_step) ? 1 : 0;
+    out[5] = (M % 2 == 0 && !env_single && !g_force_single_step) ? (pl.pipe ? 2 : 1) : 0;
     return 0;
 }
 

@@ -198,7 +198,7 @@ class Context:
         out = (_I * 6)()
         self.check(self.lib.sbtv_diag_prox_variant(self.h, int(M), int(N), int(batch), out))
         return dict(cols_per_wave=out[0], waves=out[1], waves_per_simd=out[2], rows_per_lane=out[3], tiles=out[4],
-                    fused=bool(out[5]))
+                    fused=bool(out[5]), kind={0: "single-step", 1: "tile", 2: "pipeline"}[out[5]])
 
     def last_timing(self):
         out = (C.c_double * 4)()

@@ -45,8 +45,10 @@ def ssim(A, ref, dynamic_range=1.0, return_map=False):
 
 
 def save_results(path, results, **extra):
-    """The legacy scripts `save` their results struct to a .mat (SALSA/salsa_m.m:346, run_deblur_tv.m:169);
-    here a results dict (as returned by SAPG_algorithm_* / SALSA_v2 wrappers) goes to a compressed .npz."""
+    """The legacy scripts `save` their results struct to a .mat (SALSA/salsa_m.m:346, run_deblur_tv.m:169).
+    A path ending in `.mat` writes a MATLAB v5 file whose variables are the fields of the results dict (as returned
+    by the SAPG_algorithm_* / SALSA_v2 wrappers; arrays keep their MATLAB orientation, traces are row vectors), so
+    `load results.mat` gives the reference's field names back; any other path writes a compressed `.npz`."""
     flat = {}
     for k, v in dict(results, **extra).items():
         if isinstance(v, dict):
@@ -55,11 +57,26 @@ def save_results(path, results, **extra):
             flat[k] = np.asarray(v)
         except Exception:
             pass
+    if str(path).lower().endswith(".mat"):
+        from scipy.io import savemat
+        savemat(path, {k: (v if v.ndim != 1 else v[None, :]) for k, v in flat.items() if v.dtype != object},
+                do_compression=True, oned_as="row")
+        return path
     np.savez_compressed(path, **flat)
     return path
 
 
 def load_results(path):
+    if str(path).lower().endswith(".mat"):
+        from scipy.io import loadmat
+        z = loadmat(path)
+        out = {}
+        for k, v in z.items():
+            if k.startswith("__"):
+                continue
+            v = np.asarray(v)
+            out[k] = v.item() if v.size == 1 else (v[0] if v.ndim == 2 and v.shape[0] == 1 else v)
+        return out
     with np.load(path, allow_pickle=False) as z:
         return {k: (z[k].item() if z[k].ndim == 0 else z[k]) for k in z.files}
 

@@ -18,8 +18,14 @@ TOL = dict(rtol=1e-12, atol=1e-12)
 
 
 def _assert_default_geometry(ctx, M, N, batch=1):
+    """These sizes take the default-geometry TILE kernel - or, when the whole file is re-run with SBTV_PROX_PIPE=1
+    (test_pipeline_kernel_passes_the_prox_parity_suite), the streaming pipeline kernel."""
+    import os
     v = ctx.prox_variant(M, N, batch)
-    assert v["fused"] and (v["cols_per_wave"], v["waves"], v["waves_per_simd"], v["rows_per_lane"]) == (4, 8, 4, 2), v
+    if os.environ.get("SBTV_PROX_PIPE") == "1":
+        assert v["kind"] == "pipeline", v
+        return v
+    assert v["kind"] == "tile" and (v["cols_per_wave"], v["waves"], v["waves_per_simd"], v["rows_per_lane"]) == (4, 8, 4, 2), v
     assert v["tiles"] * batch >= 256, v
     return v
 
@@ -133,3 +139,47 @@ def test_default_fused_kernel_batch_of_two_1024(ctx):
     want0 = o.chambolle_prox_TV_stop(g[0], lam=6.0, maxiter=10, return_info=True)
     _compare((f[0], px[0], py[0], k[:1], err[:1]), want0)
     assert k[1] == 1 and err[1] == 0.0 and np.array_equal(f[1], g[1])      # constant image: err = 0 at k = 1
+
+
+def test_pipeline_kernel_2048_matches_oracle(ctx, man512):
+    """The streaming pipeline kernel (csrc/tv_pipe.inc, opt-in) at the benchmark size: 19 bands x 13 column segments,
+    ten iterations per launch.  Cold K = 10 with f, then warm-started K = 10 on a changed g (what
+    SALSA_v2.m:429 does every outer iteration), then K = 25 cold (three launches: 9 + 8 + 8) against the oracle."""
+    import os
+    import sbtv
+    import sbtv_oracle as o
+    if os.environ.get("SBTV_PROX_PIPE") != "1":
+        pytest.skip("runs in the child process of test_pipeline_kernel_passes_the_prox_parity_suite (SBTV_PROX_PIPE=1)")
+    M = N = 2048
+    v = ctx.prox_variant(M, N, 1)
+    assert v["kind"] == "pipeline" and v["tiles"] <= 256, v
+    g = np.tile(man512, (4, 4)) + np.random.default_rng(41).standard_normal((M, N))
+    lam = 9.0
+    gd = sbtv.to_device(g)
+    got = sbtv.chambolle_prox_TV_stop(gd, "lambda", lam, "maxiter", 10, return_info=True)
+    want = o.chambolle_prox_TV_stop(g, lam=lam, maxiter=10, return_info=True)
+    _compare((sbtv.to_host(got[0]), sbtv.to_host(got[1]), sbtv.to_host(got[2]), got[3], got[4]), want)
+    g2 = g + 0.7 * np.random.default_rng(42).standard_normal((M, N))
+    got2 = sbtv.chambolle_prox_TV_stop(sbtv.to_device(g2), "lambda", lam, "maxiter", 10, "dualvars", (got[1], got[2]),
+                                       return_info=True)
+    want2 = o.chambolle_prox_TV_stop(g2, lam=lam, maxiter=10, dualvars=(want[1], want[2]), return_info=True)
+    _compare((sbtv.to_host(got2[0]), sbtv.to_host(got2[1]), sbtv.to_host(got2[2]), got2[3], got2[4]), want2)
+    got3 = sbtv.chambolle_prox_TV_stop(gd, "lambda", lam, "maxiter", 25, return_info=True)
+    want3 = o.chambolle_prox_TV_stop(g, lam=lam, maxiter=25, return_info=True)
+    _compare((sbtv.to_host(got3[0]), sbtv.to_host(got3[1]), sbtv.to_host(got3[2]), got3[3], got3[4]), want3)
+
+
+def test_pipeline_kernel_passes_the_prox_parity_suite():
+    """Every TV-prox parity test of this file and of test_gpu_tv.py (ragged sizes from 2 x 2, warm start, batch,
+    early exit, the stop rule firing inside / between launches) once more with the streaming pipeline kernel forced
+    for every even M (SBTV_PROX_PIPE=1 is read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SBTV_PROX_PIPE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_tv.py"),
+                        os.path.join(root, "tests", "test_gpu_tv_large.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "not passes_the_prox_parity_suite"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

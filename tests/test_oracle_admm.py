@@ -128,6 +128,15 @@ def test_results_round_trip(tmp_path):
     np.testing.assert_array_equal(back["thetas"], res["thetas"])
     np.testing.assert_array_equal(back["xMAP"], res["xMAP"])
     assert "options" not in back
+    # .mat (what SALSA/salsa_m.m:346 `save`s): MATLAB v5 file with the reference's field names as variables
+    pm = d.save_results(str(tmp_path / "res.mat"), res, psnr=30.5)
+    from scipy.io import loadmat
+    raw = loadmat(pm)
+    assert raw["thetas"].shape == (1, 5) and raw["xMAP"].shape == (4, 3)      # traces are row vectors in MATLAB
+    backm = d.load_results(pm)
+    assert backm["theta_EB"] == 0.0123 and backm["psnr"] == 30.5
+    np.testing.assert_array_equal(backm["thetas"], res["thetas"])
+    np.testing.assert_array_equal(backm["xMAP"], res["xMAP"])
 
 
 def test_trace_plot_and_image_files(tmp_path):

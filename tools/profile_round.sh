@@ -4,7 +4,7 @@
 # 1. plain bench line                      -> profiles/<tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats      -> profiles/<tag>_kernel_stats.csv
 # 3. three separate --pmc passes (SQ activity / FETCH_SIZE / WRITE_SIZE; never combined with tracing)
-#                                          -> profiles/<tag>_pmc.json, profiles/r01_pmc_chambolle.json
+#                                          -> profiles/<tag>_pmc.json, profiles/pmc_current.json
 set -eo pipefail
 TAG=${1:?tag}
 R=$PWD
@@ -28,6 +28,6 @@ echo "pmc write done"
 cd "$R"
 python3 tools/summarize_profiles.py "$TAG" "$O/stats" "$O/pmc_sq" "$O/pmc_fetch" "$O/pmc_write"
 mkdir -p gpurun_out/profiles_$TAG
-cp profiles/${TAG}_* profiles/r01_pmc_chambolle.json gpurun_out/profiles_$TAG/
+cp profiles/${TAG}_* profiles/pmc_current.json gpurun_out/profiles_$TAG/
 # the raw traces are large: keep only the summaries in gpurun_out
 rm -rf "$O/stats" "$O/pmc_sq" "$O/pmc_fetch" "$O/pmc_write"

@@ -6,8 +6,10 @@ files committed under profiles/.
 
 Writes profiles/<tag>_kernel_stats.csv (per-kernel calls / avg / share; fused Chambolle launches split
 into real and empty (redo no-op) launches) and, when PMC passes are given, profiles/<tag>_pmc.json
-plus profiles/r01_pmc_chambolle.json (HBM bytes per real launch of the dominant kernel, with the
-gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md §HBM; bench.py reads it for `roofline.traffic`).
+plus profiles/pmc_current.json: what bench.py needs for its roofline entries - per kernel of the SALSA loop the
+VALU wave-instructions and the HBM-side bytes of one real launch (2 x FETCH_SIZE + WRITE_SIZE: the gfx950
+correction of MI355X_MICROARCH.md §HBM), the bytes of one outer iteration, and the SHA-256 of the kernel sources
+the numbers were measured on (bench.py refuses the file when the sources have changed since).
 """
 import collections
 import csv
@@ -61,19 +63,38 @@ def main():
                     res.setdefault(k, {})[c] = {"n": len(v), "mean": sum(v) / len(v), "max": max(v)}
         with open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w") as f:
             json.dump(res, f, indent=1, sort_keys=True)
-        ck = [k for k in res if k.startswith("chambolle_fused_kernel")]
+        sys.path.insert(0, ROOT)
+        import bench
+        loop = ("chambolle_fused_kernel", "chambolle_pipe_kernel", "chambolle_fused_ctrl_kernel", "fft_cols_fwd_kernel",
+                "cols_fwd_wave_kernel", "fft_rows_kernel", "rows_wave_kernel", "fft_cols_inv_kernel",
+                "cols_inv_wave_kernel", "salsa_collect_kernel")
+        n_outer = max(len(per.get(k, [])) for k in per if k.startswith("salsa_collect_kernel"))
+        kernels, total = {}, 0.0
+        for k, c in res.items():
+            if not k.startswith(loop) or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            # launches that do nothing (the empty redo pass of the prox) move no data: the max is a real launch,
+            # mean x n the sum over all launches
+            f_kb, w_kb = c["FETCH_SIZE"], c["WRITE_SIZE"]
+            real = 2 * f_kb["max"] * 1024 + w_kb["max"] * 1024
+            total += (2 * f_kb["mean"] * f_kb["n"] + w_kb["mean"] * w_kb["n"]) * 1024
+            kernels[k] = {"hbm_bytes_per_launch": real, "fetch_size_kb_raw": f_kb["max"], "write_size_kb": w_kb["max"],
+                          "valu_insts_per_launch": c.get("SQ_INSTS_VALU", {}).get("max"),
+                          "active_valu_quadcycles": c.get("SQ_ACTIVE_INST_VALU", {}).get("max"),
+                          "wave_cycles": c.get("SQ_WAVE_CYCLES", {}).get("max"), "wait_any": c.get("SQ_WAIT_ANY", {}).get("max"),
+                          "launches_profiled": f_kb["n"]}
+        ck = [k for k in kernels if k.startswith("chambolle_fused_kernel")]
         if ck:
-            c = res[ck[0]]
-            # every third launch is an empty redo pass (moves no data): the max over launches is a real launch
-            fetch_kb, write_kb = c["FETCH_SIZE"]["max"], c["WRITE_SIZE"]["max"]
-            d = {"kernel": ck[0], "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
-                 "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-                 "note": "per real 5-iteration launch at 2048x2048; FETCH_SIZE doubled (gfx950 reports 1/2 of wide "
-                         "coalesced reads, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are included in "
-                         "these fabric counters, so this is an upper bound on true HBM traffic"}
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_chambolle.json"), "w") as f:
-                json.dump(d, f, indent=1)
-            print(d)
+            kernels[ck[0]]["core_fraction"] = (116.0 * 21.0) / (128.0 * 32.0)   # core / region of the 4x8 tile geometry
+        d = {"tag": tag, "source_sha256": bench.source_sha(), "image": [bench.SIZE, bench.SIZE],
+             "outer_iterations_profiled": n_outer, "bytes_per_outer_iteration": total / max(n_outer, 1),
+             "kernels": kernels,
+             "note": "rocprofv3 --pmc passes of `bench.py --steps 30 --warmup 5` (separate SQ / FETCH_SIZE / WRITE_SIZE "
+                     "passes); bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports 1/2 of wide coalesced reads, "
+                     "MI355X_MICROARCH.md HBM section); fabric-side counters: Infinity-Cache hits are included"}
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json"), "w") as f:
+            json.dump(d, f, indent=1, sort_keys=True)
+        print(json.dumps({k: v for k, v in d.items() if k != "kernels"}))
 
 
 if __name__ == "__main__":
