@@ -142,11 +142,21 @@ def model_step_bytes(size):
 
 
 def pass_block(ctx, size, names, reps):
+    """Stand-alone HIP-event timings of single passes on scratch data (inputs then still sit in the caches: the
+    kernels run 5-20 % slower inside the solver loop, profiles/r02_fft_lab.md)."""
     out = {}
+    kind = ctx.prox_variant(size, size)["kind"]
     for nm in names:
         r = ctx.time_pass(nm, size, size, 1, reps)
-        out[nm] = {"ms": r["ms"], "algorithmic_bytes": r["bytes"], "achieved_gbs": r["gbs"],
-                   "frac_of_hbm_peak": r["gbs"] / HBM_PEAK_GBS}
+        by = r["bytes"]
+        if nm.startswith("prox"):
+            # temporally fused prox: the bytes of the fused design (every launch reads g,px,py and writes px,py once,
+            # the last one also writes f), not K x 40 B/px of an unfused sweep - that count exceeds what HBM could move
+            its = 10 if nm == "prox10_warm" else 25
+            per = 10 if kind == "pipeline" else FUSED_STEPS
+            by = (40.0 * -(-its // per) + 8.0) * size * size
+        gbs = by / (r["ms"] * 1e-3) / 1e9
+        out[nm] = {"ms": r["ms"], "model_bytes": by, "achieved_gbs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
     return out
 
 

@@ -1242,7 +1242,12 @@ int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int re
             default: return fail(ctx, SBTV_ERR_BADARG, "sbtv_diag_time_pass: unknown pass");
         }
     };
-    if (pass == 7) SBTV_TRY(prox_zero_duals(ctx, pp));
+    if (pass == 7) {
+        // warm start: zero duals in slot 0 and a control block that SELECTS slot 0 (a fresh control buffer holds
+        // garbage, and `keep_cur` below would then index the dual buffer with it)
+        SBTV_TRY(prox_zero_duals(ctx, pp));
+        SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, 10, 1e-3, 0.249, false, nullptr));
+    }
     for (int w = 0; w < 2; ++w) SBTV_TRY(once());
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     for (int r = 0; r < reps; ++r) SBTV_TRY(once());

@@ -90,10 +90,10 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
     if (c.done) return;
     const size_t P = (size_t)M * N;
     const size_t plane = P * batch;
-    const double *__restrict__ pxi = pbuf + (size_t)(c.cur * 2 + 0) * plane + (size_t)b * P;
-    const double *__restrict__ pyi = pbuf + (size_t)(c.cur * 2 + 1) * plane + (size_t)b * P;
-    double *__restrict__ pxo = pbuf + (size_t)((c.cur ^ 1) * 2 + 0) * plane + (size_t)b * P;
-    double *__restrict__ pyo = pbuf + (size_t)((c.cur ^ 1) * 2 + 1) * plane + (size_t)b * P;
+    const double *__restrict__ pxi = pbuf + (size_t)((c.cur & 1) * 2 + 0) * plane + (size_t)b * P;
+    const double *__restrict__ pyi = pbuf + (size_t)((c.cur & 1) * 2 + 1) * plane + (size_t)b * P;
+    double *__restrict__ pxo = pbuf + (size_t)(((c.cur & 1) ^ 1) * 2 + 0) * plane + (size_t)b * P;
+    double *__restrict__ pyo = pbuf + (size_t)(((c.cur & 1) ^ 1) * 2 + 1) * plane + (size_t)b * P;
     const double *__restrict__ gg = g + (size_t)b * P;
     const double lambda = c.lambda, tau = c.tau;
 
@@ -419,7 +419,7 @@ __global__ void prox_reset_kernel(ProxCtrl *__restrict__ ctrl, const double *__r
     ProxCtrl c = ctrl[b];
     c.k = 0;
     c.done = (frozen && frozen[b]) ? 1 : 0;
-    if (!keep_cur) c.cur = 0;
+    c.cur = keep_cur ? (c.cur & 1) : 0;      // never anything but 0 or 1, whatever the buffer held
     c.maxiter = maxiter;
     c.redo = 0;
     c.f_valid = 0;
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(TVB) void chambolle_finish_kernel(const double *__r
     const ProxCtrl c = ctrl[b];
     const size_t P = (size_t)M * N;
     const size_t plane = P * batch;
-    const double *__restrict__ px = pbuf + (size_t)(c.cur * 2 + 0) * plane + (size_t)b * P;
-    const double *__restrict__ py = pbuf + (size_t)(c.cur * 2 + 1) * plane + (size_t)b * P;
+    const double *__restrict__ px = pbuf + (size_t)((c.cur & 1) * 2 + 0) * plane + (size_t)b * P;
+    const double *__restrict__ py = pbuf + (size_t)((c.cur & 1) * 2 + 1) * plane + (size_t)b * P;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * TI + 2 * lane;
     const bool ok0 = i < M, ok1 = i + 1 < M;
@@ -517,8 +517,8 @@ __global__ void copy_duals_kernel(double *__restrict__ dst0, double *__restrict_
     const int b = blockIdx.y;
     const ProxCtrl c = ctrl[b];
     const size_t plane = P * batch;
-    const double *px = pbuf + (size_t)(c.cur * 2 + 0) * plane + (size_t)b * P;
-    const double *py = pbuf + (size_t)(c.cur * 2 + 1) * plane + (size_t)b * P;
+    const double *px = pbuf + (size_t)((c.cur & 1) * 2 + 0) * plane + (size_t)b * P;
+    const double *py = pbuf + (size_t)((c.cur & 1) * 2 + 1) * plane + (size_t)b * P;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < P; q += (size_t)gridDim.x * blockDim.x) {
         dst0[(size_t)b * P + q] = px[q];
         dst1[(size_t)b * P + q] = py[q];

@@ -15,7 +15,7 @@ python3 bench.py --steps 200 --warmup 20 > "$O/bench.json" 2> "$O/bench.err"
 cp "$O/bench.json" "$R/gpurun_out/${TAG}_bench.json"
 echo "bench done"; tail -c 600 "$O/bench.json"; echo
 cd /tmp
-B="$R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-batched"   # single-image launches only
+B="$R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-batched --no-extras"   # 2048^2 single-image launches only
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 $B > "$O/stats.log" 2>&1
 echo "kernel trace done"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
