@@ -44,6 +44,9 @@ extern "C" {
 /* flags */
 #define SBTV_HOST_PTRS   0
 #define SBTV_DEVICE_PTRS 1
+/* sbtv_SAPG_algorithm only: */
+#define SBTV_REDUCE_DEVICE  2   /* reduce_fn is an sbtv_allreduce_dev_fn (in-stream collective on a device buffer)  */
+#define SBTV_SAPG_HOST_LOOP 4   /* parameter updates on the host, one synchronisation per iteration (the round-1 loop) */
 
 /* status codes */
 #define SBTV_OK                   0
@@ -269,8 +272,20 @@ typedef struct sbtv_sapg_opts {
  *          buf = {sum G_theta, sum G_p0, sum G_p1, sum G_sigma, chains, failed ranks}: a rank whose iteration
  *          failed locally still calls reduce_fn (with failed = 1) before it returns its error, and every other
  *          rank then returns SBTV_ERR_PEER, so no rank is left waiting inside the collective.  Every rank must
- *          run at least one chain (batch >= 1). */
+ *          run at least one chain (batch >= 1).
+ *   The loop itself (SAPG_algorithm_Guassian.m:98-248) is device-resident: the gradients G_theta, G_p, G_sigma
+ *          (:165-188), the projected updates (:166-194), the PSF taps of the new parameters and the traces are
+ *          computed by a one-workgroup kernel at the end of every iteration, so the host enqueues iterations without
+ *          waiting for them (one synchronisation per 1024 iterations and at the end).  A host `reduce_fn` needs the
+ *          scalars on the host and therefore selects the host-side loop (as does SBTV_SAPG_HOST_LOOP): identical
+ *          arithmetic for theta / p / sigma; the PSF taps then come from the host's libm instead of the device's
+ *          (differences in the last bit of exp / pow).  With SBTV_REDUCE_DEVICE `reduce_fn` must be an
+ *          sbtv_allreduce_dev_fn: it is called once per iteration with the DEVICE address of the same 6 doubles and
+ *          the library's stream and must enqueue an in-place SUM over the processes that is ordered after the work
+ *          already in that stream and before work enqueued later (e.g. ncclAllReduce / torch.distributed.all_reduce
+ *          on that stream); it must not wait for the GPU.  In that mode a failing rank returns its error at once. */
 typedef int (*sbtv_allreduce_fn)(void *user, double *buf, int n);
+typedef int (*sbtv_allreduce_dev_fn)(void *user, double *dev_buf, int n, void *hip_stream);
 int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                         const sbtv_sapg_opts *op, const double *x0, const double *noise,
                         double *thetas, double *ps, double *sigmas, double *logpi,

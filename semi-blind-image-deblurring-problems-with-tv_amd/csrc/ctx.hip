@@ -557,54 +557,11 @@ int sbtv_psf_taps(int kind, int taille, const double *p, double *taps, double *d
     if (taille < 1 || taille > 15 || !p || !taps)
         return fail(nullptr, SBTV_ERR_PSF, "sbtv_psf_taps: bad arguments (1 <= taille <= 15)");
     const int t = taille;
-    const double center = (t + 1) / 2.0;
-    std::vector<double> X(t);
-    for (int i = 0; i < t; ++i) X[i] = (-t + center) + i;   // -taille+center : taille-center
-    const double PI = 3.14159265358979323846;
+    if (kind != SBTV_PSF_GAUSSIAN && kind != SBTV_PSF_MOFFAT && kind != SBTV_PSF_LAPLACE)
+        return fail(nullptr, SBTV_ERR_PSF, "sbtv_psf_taps: unknown PSF kind");
     std::vector<double> f(t * t), e0(t * t, 0.0), e1(t * t, 0.0);
     double s = 0, s0 = 0, s1 = 0;
-    if (kind == SBTV_PSF_GAUSSIAN) {
-        // utils/Gaussian_psf.m:2-19 ; Sum_gauss_psf.m:1-28 ; diff_fftgaus_w1.m / w2.m
-        const double w1 = p[0], w2 = p[1], phi = p[2];
-        for (int jj = 0; jj < t; ++jj)
-            for (int ii = 0; ii < t; ++ii) {
-                const double v = X[ii], u = X[jj];   // ndgrid: v rows, u columns
-                const double U = u * cos(phi) - v * sin(phi);
-                const double V = u * sin(phi) + v * cos(phi);
-                const double c = w1 * w1 * (U * U) + w2 * w2 * (V * V);
-                const double ex = exp(-c / 2);
-                const int q = jj * t + ii;
-                f[q] = ((w1 * w2) / (2 * PI)) * ex;
-                e0[q] = (w2 / (2 * PI)) * (1 - w1 * w1 * (U * U)) * ex;
-                e1[q] = (w1 / (2 * PI)) * (1 - w2 * w2 * (V * V)) * ex;
-            }
-    } else if (kind == SBTV_PSF_MOFFAT) {
-        // utils/psf_moffat.m:2-20 ; sum_mof_psf.m:1-40 ; diff_moffat_alpha.m ; diff_moffat_beta.m
-        const double a = p[0], b = p[1], b2 = b + 2;
-        for (int jj = 0; jj < t; ++jj)
-            for (int ii = 0; ii < t; ++ii) {
-                const double xy = X[ii] * X[ii] + X[jj] * X[jj];
-                const int q = jj * t + ii;
-                f[q] = a * a * pow((xy * (a * a)) / b + 1, -b2 / 2) / (2 * PI);
-                e0[q] = (2 - (((b + 2) * xy * (a * a)) / (2 * (b + xy * (a * a))))) *
-                        pow(1 + xy * (a * a) / b, -(b + 2) / 2) * (a / (2 * PI));
-                const double cons1 = (a * a) / (4 * PI);
-                e1[q] = (-log(xy * (a * a) / b + 1) + (b2 * xy * (a * a)) / (b * (b + xy * (a * a)))) *
-                        pow(xy * (a * a) / b + 1, -b2 / 2) * cons1;
-            }
-    } else if (kind == SBTV_PSF_LAPLACE) {
-        // utils/psf_laplace.m:1-13 ; sum_lap_psf.m:1-28 ; diff_laplace_b.m:1-19
-        const double b = p[0];
-        for (int jj = 0; jj < t; ++jj)
-            for (int ii = 0; ii < t; ++ii) {
-                const double sa = fabs(X[ii]) + fabs(X[jj]);
-                const int q = jj * t + ii;
-                f[q] = ((b * b) / 4) * exp(-b * sa);
-                e0[q] = ((2 * b - (b * b) * sa) / 4) * exp(-b * sa);
-            }
-    } else {
-        return fail(nullptr, SBTV_ERR_PSF, "sbtv_psf_taps: unknown PSF kind");
-    }
+    for (int q = 0; q < t * t; ++q) psf_taps_point(kind, t, p, q, &f[q], &e0[q], &e1[q]);   // psf_taps.inc
     // MATLAB sum(sum(.)) / sum(k(:)) : column-major accumulation order
     for (int q = 0; q < t * t; ++q) { s += f[q]; s0 += e0[q]; s1 += e1[q]; }
     for (int q = 0; q < t * t; ++q) {

@@ -78,6 +78,167 @@ __global__ __launch_bounds__(256) void fista_collect_kernel(const double *__rest
     if (threadIdx.x == 0) out[o] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- device-resident SAPG parameter update (SAPG_algorithm_Guassian.m:165-248 and twins) ------------------------
+// State of one chain and the constants of a run; the kernel below is the host-side arithmetic of the round-1 loop moved
+// to the device, operation for operation (no FMA contraction: theta / p / sigma traces are bit-identical to the host
+// loop for the same scalars), so that no iteration has to wait for the host.
+struct SapgChain {
+    double theta, p0, p1, sig2, sum_th, sum_p0, sum_p1, sum_s;
+};
+struct SapgDev {
+    int kind, taille, npar, nspec, batch, shared, samples, warmup, burnIn, params_move, fix_p0, fix_p1, fix_sigma;
+    double dimX, parseval, lamb, c_theta, c_p0, c_p1, c_sigma, min_th, max_th, p_min0, p_max0, p_min1, p_max1, p_true0,
+        p_true1, s_lo, s_hi, sigma2_init, phi, step_base;
+    const double *scal;        // [4*batch] totals of the collector: ||AX-y||^2, <dA_p0 X, r>, <dA_p1 X, r> per chain, TV
+    SapgChain *chain;          // [batch]
+    double *par;               // [taps | d0 | d1] per spectrum set, lam[batch], sigma2[batch], noise step
+    const double *delta;       // [samples + 1]: delta(ii) of :55, tabulated by the host (pow)
+    int *it;                   // [0] ii of the SAPG iteration in flight, [1] ii of the warm-up iteration in flight
+    double *red;               // [6] shared-gradient sums (the all-reduce buffer)
+    double *G;                 // [batch*4] per-chain gradients
+    double *tr_theta, *tr_p, *tr_sigma, *tr_logpi, *tr_gx, *tr_grads, *tr_wu;   // device traces, layouts of sbtv.h
+};
+enum { SAPG_PH_GRADS = 1, SAPG_PH_UPDATE = 2, SAPG_PH_WARMUP = 4 };
+
+__global__ __launch_bounds__(256) void sapg_update_kernel(SapgDev u, int phase) {
+#pragma clang fp contract(off)
+    __shared__ double sf[225], se0[225], se1[225], ssum[3];
+    const int B = u.batch, tid = threadIdx.x, t2 = u.taille * u.taille;
+    double *lam_d = u.par + (size_t)3 * t2 * u.nspec, *sig_d = lam_d + B, *step_d = sig_d + B;
+    if (phase & SAPG_PH_WARMUP) {
+        // logPiTrace_WU(ii) of the warm-up iteration that just finished (:85); theta and sigma do not move here
+        const int ii = u.it[1];
+        for (int b = tid; b < B; b += 256) {
+            const SapgChain c = u.chain[b];
+            const double resid2 = u.scal[(size_t)b * 3] * u.parseval;
+            u.tr_wu[(size_t)b * u.warmup + (ii - 1)] = -resid2 / (2 * c.sig2) - c.theta * u.scal[3 * (size_t)B + b];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u.it[1] = ii + 1;
+            *step_d = (double)(ii - 1);          // noise step of warm-up iteration ii+1 (steps count from 0 at ii = 2)
+        }
+        return;
+    }
+    const int ii = u.it[0], i0 = ii - 1;
+    if (phase & SAPG_PH_GRADS) {
+        for (int b = tid; b < B; b += 256) {
+            const SapgChain c = u.chain[b];
+            const double resid2 = u.scal[(size_t)b * 3] * u.parseval;
+            const double tv = u.scal[3 * (size_t)B + b];
+            u.G[b * 4 + 0] = u.dimX / c.theta - tv;                                                   // :165
+            u.G[b * 4 + 1] = (u.scal[(size_t)b * 3 + 1] * u.parseval) / c.sig2;                       // :170
+            u.G[b * 4 + 2] = (u.scal[(size_t)b * 3 + 2] * u.parseval) / c.sig2;                       // :179
+            u.G[b * 4 + 3] = resid2 / (2 * c.sig2 * c.sig2) - u.dimX / (2 * c.sig2);                  // :188
+            u.tr_logpi[(size_t)b * u.samples + i0] = -resid2 / (2 * c.sig2) - c.theta * tv;           // :207
+            u.tr_gx[(size_t)b * u.samples + (i0 - 1)] = tv;                                           // :208
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (u.shared && tid == 0) {
+            // the chains sample one posterior: G = mean over the chains (SAPG_algorithm_moffat.m:158-173), summed
+            // here in chain order; the sums of the other ranks are added by the all-reduce between the two phases
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int b = 0; b < B; ++b) {
+                a0 += u.G[b * 4 + 0];
+                a1 += u.G[b * 4 + 1];
+                a2 += u.G[b * 4 + 2];
+                a3 += u.G[b * 4 + 3];
+            }
+            u.red[0] = a0;
+            u.red[1] = a1;
+            u.red[2] = a2;
+            u.red[3] = a3;
+            u.red[4] = (double)B;
+            u.red[5] = 0.0;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (!(phase & SAPG_PH_UPDATE)) return;
+    const double delta = u.delta[ii];
+    for (int b = tid; b < B; b += 256) {
+        SapgChain c = u.chain[b];
+        double Gt, Gp0, Gp1, Gs;
+        if (u.shared) {
+            Gt = u.red[0] / u.red[4];
+            Gp0 = u.red[1] / u.red[4];
+            Gp1 = u.red[2] / u.red[4];
+            Gs = u.red[3] / u.red[4];
+        } else {
+            Gt = u.G[b * 4 + 0];
+            Gp0 = u.G[b * 4 + 1];
+            Gp1 = u.G[b * 4 + 2];
+            Gs = u.G[b * 4 + 3];
+        }
+        const double th_new = fmin(fmax(c.theta + u.c_theta * delta * Gt, u.min_th), u.max_th);       // :166-167
+        double q0 = u.fix_p0 ? u.p_true0 : c.p0 - u.c_p0 * delta * Gp0;                               // :171-176
+        q0 = fmin(fmax(q0, u.p_min0), u.p_max0);
+        double q1 = c.p1;
+        if (u.npar > 1) {
+            q1 = u.fix_p1 ? u.p_true1 : c.p1 - u.c_p1 * delta * Gp1;                                  // :180-185
+            q1 = fmin(fmax(q1, u.p_min1), u.p_max1);
+        }
+        double s_new = u.fix_sigma ? u.sigma2_init : c.sig2 + u.c_sigma * delta * Gs;                 // :189-194
+        s_new = fmin(fmax(s_new, u.s_lo), u.s_hi);
+        u.tr_grads[((size_t)b * 4 + 0) * u.samples + i0] = Gt;
+        u.tr_grads[((size_t)b * 4 + 1) * u.samples + i0] = Gp0;
+        u.tr_grads[((size_t)b * 4 + 2) * u.samples + i0] = Gp1;
+        u.tr_grads[((size_t)b * 4 + 3) * u.samples + i0] = Gs;
+        u.tr_theta[(size_t)b * u.samples + i0] = th_new;
+        u.tr_sigma[(size_t)b * u.samples + i0] = s_new;
+        u.tr_p[((size_t)b * 2 + 0) * u.samples + i0] = q0;
+        u.tr_p[((size_t)b * 2 + 1) * u.samples + i0] = q1;
+        c.theta = th_new;
+        c.p0 = q0;
+        c.p1 = q1;
+        c.sig2 = s_new;
+        if (ii >= u.burnIn) {
+            c.sum_th += th_new;
+            c.sum_s += s_new;
+            c.sum_p0 += q0;
+            c.sum_p1 += q1;
+        }
+        u.chain[b] = c;
+        lam_d[b] = u.lamb * th_new;          // proxG(x, theta): 'lambda', op.lambda*theta  (run_Gaussian_demo.m:191)
+        sig_d[b] = s_new;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (u.params_move) {
+        // taps and derivative taps of the new PSF parameters, one spectrum set after the other (sbtv_psf_taps)
+        for (int sset = 0; sset < u.nspec; ++sset) {
+            const SapgChain c = u.chain[sset];
+            const double pv[3] = {c.p0, u.kind == 2 ? 0.0 : c.p1, u.kind == 0 ? u.phi : 0.0};
+            if (tid < t2) psf_taps_point(u.kind, u.taille, pv, tid, &sf[tid], &se0[tid], &se1[tid]);
+            __syncthreads();
+            if (tid == 0) {
+                double a = 0, a0 = 0, a1 = 0;     // MATLAB sum(k(:)): column-major order
+                for (int q = 0; q < t2; ++q) {
+                    a += sf[q];
+                    a0 += se0[q];
+                    a1 += se1[q];
+                }
+                ssum[0] = a;
+                ssum[1] = a0;
+                ssum[2] = a1;
+            }
+            __syncthreads();
+            if (tid < t2) {
+                const double a = ssum[0];
+                u.par[(size_t)sset * t2 + tid] = sf[tid] / a;
+                u.par[(size_t)t2 * u.nspec + (size_t)sset * t2 + tid] = (se0[tid] * a - sf[tid] * ssum[1]) / (a * a);
+                u.par[(size_t)2 * t2 * u.nspec + (size_t)sset * t2 + tid] = (se1[tid] * a - sf[tid] * ssum[2]) / (a * a);
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        u.it[0] = ii + 1;
+        *step_d = u.step_base + (double)(ii - 1);    // noise step of SAPG iteration ii+1
+    }
+}
+
 // sums of the rows-kernel accumulators: out[b*3 + c]
 static int reduce_acc(sbtv_ctx *ctx, const double *acc, int batch, int nrb, double *out_dev) {
     return reduce_partials(ctx, acc, batch * 3, nrb, out_dev);
@@ -506,6 +667,31 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     const double inv_scale = 1.0 / ((double)fp.n1 * N), parseval = 1.0 / ((double)M * N);
     const double lamb = op->lambda, gam = op->gamma;
 
+    // ---- where the parameter updates run.  Default: on the device (sapg_update_kernel), the host only enqueues.
+    // A host reduce_fn needs the gradients on the host every iteration, which selects the host-side loop below.
+    static const bool env_host_loop = [] {
+        const char *e = getenv("SBTV_SAPG_HOST");
+        return e && e[0] == '1';
+    }();
+    const bool reduce_dev = reduce_fn && (flags & SBTV_REDUCE_DEVICE);
+    const bool dev_loop = !(flags & SBTV_SAPG_HOST_LOOP) && !env_host_loop && (!reduce_fn || reduce_dev);
+    if (reduce_dev && !dev_loop)
+        return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: SBTV_REDUCE_DEVICE needs the device-resident loop (no SBTV_SAPG_HOST_LOOP)");
+    double *scal_d = nullptr, *delta_d = nullptr, *red_d = nullptr, *G_d = nullptr, *tr_d = nullptr;
+    SapgChain *chain_d = nullptr;
+    int *it_d = nullptr;
+    const size_t ntr = (size_t)batch * samples * 10 + (size_t)batch * (warmup > 0 ? warmup : 1);
+    if (dev_loop) {
+        SBTV_TRY(ws_get_t(ctx, "sapg.scal", 4 * (size_t)batch, &scal_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.delta", (size_t)samples + 1, &delta_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.red", 8, &red_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.G", 4 * (size_t)batch, &G_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.traces", ntr, &tr_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.chain", (size_t)batch, &chain_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.it", 2, &it_d));
+    }
+    double *scal_out = dev_loop ? scal_d : scal_hd;   // where the collector leaves the scalars of an iteration
+
     // ---- chain state (host scalars)
     std::vector<double> theta(batch, op->th_init), sig2(batch, op->sigma2_init);
     std::vector<double> p0(batch, op->p_init[0]), p1(batch, npar > 1 ? op->p_init[1] : 0.0);
@@ -571,12 +757,13 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         int ntv = 0;
         SBTV_TRY(tvnorm_partials(ctx, X, M, N, batch, &tvp, &ntv));
         hipLaunchKernelGGL(sapg_collect_kernel, dim3(4, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
-                           (const double *)tvp, ntv, scal_hd, batch);
+                           (const double *)tvp, ntv, scal_out, batch);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
     auto fetch_scalars = [&]() -> int {
         SBTV_TRY(collect_scalars());
+        if (dev_loop) SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(double) * 4 * batch, hipMemcpyDeviceToHost, ctx->stream));
         SBTV_TRY(wait_stream(ctx));
         return 0;
     };
@@ -704,6 +891,150 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         const double resid2 = scal_h[(size_t)b * 3] * parseval;
         return -resid2 / (2 * s2) - th * scal_h[3 * (size_t)batch + b];
     };
+
+    if (dev_loop) {
+        // ================= device-resident loop: warm-up (:66-93), SAPG iterations (:98-248) =================
+        SapgDev u{};
+        u.kind = op->kind; u.taille = taille; u.npar = npar; u.nspec = nspec; u.batch = batch; u.shared = shared;
+        u.samples = samples; u.warmup = warmup > 0 ? warmup : 1; u.burnIn = op->burnIn; u.params_move = params_move ? 1 : 0;
+        u.fix_p0 = op->fix_p[0]; u.fix_p1 = op->fix_p[1]; u.fix_sigma = op->fix_sigma;
+        u.dimX = dimX; u.parseval = parseval; u.lamb = lamb; u.c_theta = op->c_theta; u.c_p0 = op->c_p[0]; u.c_p1 = op->c_p[1];
+        u.c_sigma = op->c_sigma; u.min_th = op->min_th; u.max_th = op->max_th; u.p_min0 = op->p_min[0]; u.p_max0 = op->p_max[0];
+        u.p_min1 = op->p_min[1]; u.p_max1 = op->p_max[1]; u.p_true0 = op->p_true[0]; u.p_true1 = op->p_true[1];
+        u.s_lo = fmin(op->sigma2_min, op->sigma2_max); u.s_hi = fmax(op->sigma2_min, op->sigma2_max);
+        u.sigma2_init = op->sigma2_init; u.phi = op->phi; u.step_base = (double)(warmup > 0 ? warmup - 1 : 0);
+        u.scal = scal_d; u.chain = chain_d; u.par = par; u.delta = delta_d; u.it = it_d; u.red = red_d; u.G = G_d;
+        const size_t bs = (size_t)batch * samples;
+        u.tr_theta = tr_d; u.tr_sigma = tr_d + bs; u.tr_logpi = tr_d + 2 * bs; u.tr_gx = tr_d + 3 * bs;
+        u.tr_p = tr_d + 4 * bs; u.tr_grads = tr_d + 6 * bs; u.tr_wu = tr_d + 10 * bs;
+        auto update = [&](int phase) -> int {
+            hipLaunchKernelGGL(sapg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, u, phase);
+            SBTV_HIP(ctx, hipGetLastError());
+            return 0;
+        };
+        // one iteration's device work; main = SAPG iteration (else warm-up), respec = new PSF spectra + gradF first
+        auto enqueue_iteration = [&](bool main, bool respec, bool in_graph) -> int {
+            if (respec) {
+                SBTV_TRY(psf_spectrum(ctx, fps, taps_d, taille, Hs));
+                SBTV_TRY(psf_spectrum(ctx, fps, d0_d, taille, D1s));
+                SBTV_TRY(psf_spectrum(ctx, fps, npar > 1 ? d1_d : d0_d, taille, D2s));
+                RowsArgs a{};
+                a.dir_fwd = 1;
+                a.dir_inv = 1;
+                a.op = OP_GRADF;
+                a.H = Hs;
+                a.Y = Ys;
+                a.acc = acc;
+                a.shared_spec = shared;
+                SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+                SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+                SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+            }
+            SBTV_TRY(myula(in_graph));                                                             // :80-81 / :160-161
+            SBTV_TRY(do_prox(true));                                                               // :82 / :162
+            SBTV_TRY(operator_pass(main ? !params_move : true));                                   // G_w*, G_s, f  (:170-188)
+            SBTV_TRY(collect_scalars());                                                           // incl. g(X)  (:165)
+            if (!main) return update(SAPG_PH_WARMUP);
+            if (!(shared && reduce_dev)) return update(SAPG_PH_GRADS | SAPG_PH_UPDATE);
+            SBTV_TRY(update(SAPG_PH_GRADS));
+            if (reinterpret_cast<sbtv_allreduce_dev_fn>(reduce_fn)(reduce_user, red_d, 6, (void *)ctx->stream) != 0)
+                return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: reduce_fn failed");
+            return update(SAPG_PH_UPDATE);
+        };
+        // graph replay (opt-in, small images): the body takes everything from device memory, so launches need no
+        // staging; a run with an in-stream collective launches eagerly (the collective is enqueued by the caller's code)
+        bool dev_graph = use_graph && !(shared && reduce_dev);
+        auto replay = [&](hipGraphExec_t *exec, bool main, bool *replayed) -> int {
+            *replayed = false;
+            if (!dev_graph) return 0;
+            if (!*exec) {
+                if (graph_begin(ctx) != 0 || graph_end(ctx, enqueue_iteration(main, main && params_move, true), exec) != 0) {
+                    *exec = nullptr;
+                    dev_graph = false;                 // capture unavailable: keep launching eagerly
+                    return 0;
+                }
+            }
+            ++noise_step;                              // the device counter advances by itself; keep the host's in step
+            SBTV_HIP(ctx, hipGraphLaunch(*exec, ctx->stream));
+            *replayed = true;
+            return 0;
+        };
+        // constants and initial chain state
+        {
+            std::vector<double> dl((size_t)samples + 1, 0.0);
+            for (int ii = 2; ii <= samples; ++ii) dl[ii] = op->d_scale * (pow((double)ii, -op->d_exp) / dimX);      // :55
+            std::vector<SapgChain> ch(batch);
+            for (int b = 0; b < batch; ++b) {
+                ch[b] = SapgChain{theta[b], p0[b], p1[b], sig2[b], 0.0, 0.0, 0.0, 0.0};
+                if (op->burnIn == 1) { ch[b].sum_th = theta[b]; ch[b].sum_s = sig2[b]; ch[b].sum_p0 = p0[b]; ch[b].sum_p1 = p1[b]; }
+            }
+            const int it0[2] = {2, 2};
+            SBTV_HIP(ctx, hipMemcpyAsync(delta_d, dl.data(), sizeof(double) * dl.size(), hipMemcpyHostToDevice, ctx->stream));
+            SBTV_HIP(ctx, hipMemcpyAsync(chain_d, ch.data(), sizeof(SapgChain) * batch, hipMemcpyHostToDevice, ctx->stream));
+            SBTV_HIP(ctx, hipMemcpyAsync(it_d, it0, sizeof(it0), hipMemcpyHostToDevice, ctx->stream));
+            SBTV_HIP(ctx, hipMemsetAsync(tr_d, 0, sizeof(double) * ntr, ctx->stream));
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the staging vectors go out of scope
+        }
+        SBTV_TRY(refresh_spectra());
+        SBTV_TRY(upload_lam_sigma(theta));
+        if (warmup > 0) {
+            SBTV_TRY(do_prox(false));
+            SBTV_TRY(operator_pass(true));                       // grad for the first step
+            for (int ii = 2; ii <= warmup; ++ii) {
+                bool replayed = false;
+                if (ii >= 3) SBTV_TRY(replay(&g_warm, false, &replayed));
+                if (!replayed) SBTV_TRY(enqueue_iteration(false, false, false));
+                if ((ii & 1023) == 0) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        } else {
+            SBTV_TRY(operator_pass(true));
+        }
+        // slot 0 of the traces (ii = 1): the one place where the host looks at the scalars
+        SBTV_TRY(fetch_scalars());
+        std::vector<double> logpi0(batch);
+        for (int b = 0; b < batch; ++b) logpi0[b] = log_pi(b, theta[b], sig2[b]);                  // :131
+        SBTV_TRY(do_prox(false));                                      // proxGX = proxG(X, thetas(1))   (:134)
+        for (int ii = 2; ii <= samples; ++ii) {
+            bool replayed = false;
+            if (ii >= 3) SBTV_TRY(replay(&g_main, true, &replayed));
+            if (!replayed) SBTV_TRY(enqueue_iteration(true, params_move && ii > 2, false));
+            if ((ii & 1023) == 0) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        // ---- traces, EB means (:258-284), last sample
+        std::vector<double> tr(ntr);
+        std::vector<SapgChain> ch(batch);
+        SBTV_HIP(ctx, hipMemcpyAsync(tr.data(), tr_d, sizeof(double) * ntr, hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(ch.data(), chain_d, sizeof(SapgChain) * batch, hipMemcpyDeviceToHost, ctx->stream));
+        if (x_last) {
+            SBTV_HIP(ctx, hipMemcpyAsync(x_last, X, sizeof(double) * cnt,
+                                         (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        }
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double *h_theta = tr.data(), *h_sigma = h_theta + bs, *h_logpi = h_theta + 2 * bs, *h_gx = h_theta + 3 * bs,
+                     *h_p = h_theta + 4 * bs, *h_grads = h_theta + 6 * bs, *h_wu = h_theta + 10 * bs;
+        for (int b = 0; b < batch; ++b) {
+            const size_t o = (size_t)b * samples;
+            if (thetas) { memcpy(thetas + o, h_theta + o, sizeof(double) * samples); thetas[o] = op->th_init; }
+            if (sigmas) { memcpy(sigmas + o, h_sigma + o, sizeof(double) * samples); sigmas[o] = op->sigma2_init; }
+            if (logpi) { memcpy(logpi + o, h_logpi + o, sizeof(double) * samples); logpi[o] = logpi0[b]; }
+            if (gx) memcpy(gx + o, h_gx + o, sizeof(double) * samples);
+            if (ps) {
+                memcpy(ps + 2 * o, h_p + 2 * o, sizeof(double) * 2 * samples);
+                ps[2 * o] = op->p_init[0];
+                ps[2 * o + samples] = npar > 1 ? op->p_init[1] : 0.0;
+            }
+            if (grads) memcpy(grads + 4 * o, h_grads + 4 * o, sizeof(double) * 4 * samples);
+            if (logpi_wu && warmup > 0) memcpy(logpi_wu + (size_t)b * warmup, h_wu + (size_t)b * warmup, sizeof(double) * warmup);
+            if (eb) {
+                const double cntm = (double)(samples - op->burnIn + 1);
+                eb[(size_t)b * 4 + 0] = ch[b].sum_th / cntm;
+                eb[(size_t)b * 4 + 1] = ch[b].sum_p0 / cntm;
+                eb[(size_t)b * 4 + 2] = ch[b].sum_p1 / cntm;
+                eb[(size_t)b * 4 + 3] = ch[b].sum_s / cntm;
+            }
+        }
+        return canary_epilogue(ctx, 0);
+    }
 
     // =========================== warm-up (:66-93) ===========================
     SBTV_TRY(refresh_spectra());

@@ -285,4 +285,6 @@ int myula_plain_step(sbtv_ctx *ctx, double *X, const double *prox, const double 
 int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S, const int *frozen);
 int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen);
 
+#include "psf_taps.inc"   // psf_taps_point(): PSF formulas shared by host and device
+
 }  // namespace sbtv

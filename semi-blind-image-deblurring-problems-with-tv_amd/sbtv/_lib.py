@@ -55,6 +55,10 @@ class sbtv_sapg_opts(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+# sbtv_allreduce_dev_fn (flags & REDUCE_DEVICE): (user, device address of the 6 doubles, n, hipStream_t)
+ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+REDUCE_DEVICE = 2        # include/sbtv.h SBTV_REDUCE_DEVICE
+SAPG_HOST_LOOP = 4       # include/sbtv.h SBTV_SAPG_HOST_LOOP
 
 _P = C.c_void_p
 _D = C.c_double

@@ -124,6 +124,45 @@ def make_allreduce_fn():
     return fn
 
 
+class _DeviceView:
+    """Zero-copy view of `n` doubles at a raw device address (CUDA array interface, read by torch.as_tensor)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def make_device_allreduce_fn(device=None):
+    """A `reduce_dev_fn` for sbtv_SAPG_algorithm(share_gradients=1, flags SBTV_REDUCE_DEVICE): sums the library's own
+    6-double DEVICE buffer over all ranks in place, in stream order on the library's stream, so the SAPG loop never
+    waits for the host: the buffer is wrapped as a tensor once (CUDA array interface), the library's hipStream_t as a
+    torch ExternalStream, and `all_reduce` is enqueued under that stream (RCCL orders its own stream after the work
+    already enqueued there and makes the stream wait for the collective; no host synchronisation).  With the gloo
+    backend (CPU rehearsals) torch stages the tensor through the host, which synchronises - correct, only slower."""
+    import torch
+    import torch.distributed as dist
+    r, w = rank_world()
+    if w == 1:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    views, streams = {}, {}
+
+    def fn(user, ptr, n, stream):
+        try:
+            key = (int(ptr), int(n))
+            t = views.get(key)
+            if t is None:
+                t = views[key] = torch.as_tensor(_DeviceView(ptr, n), device=dev)
+            st = streams.get(stream)
+            if st is None:
+                st = streams[stream] = torch.cuda.ExternalStream(int(stream or 0), device=dev)
+            with torch.cuda.stream(st):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return 0
+        except Exception:      # never raise through the C boundary
+            return 1
+    return fn
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -76,7 +76,13 @@ def demo_setup(kind, x, noise, evMax, BSNR=30.0, true_params=None, BSNR_min=None
                 th_init=th_init, dimX=dimX)
 
 
-def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=None, ctx=None):
+def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=None, ctx=None, reduce_dev_fn=None,
+          host_loop=False):
+    """reduce_fn(user, buf, n): host all-reduce of the shared-gradient sums (selects the host-side parameter loop);
+    reduce_dev_fn(user, dev_ptr, n, stream): in-stream all-reduce on the device buffer (`dist.make_device_allreduce_fn`),
+    the loop stays device-resident; host_loop=True forces the host-side loop (SBTV_SAPG_HOST_LOOP)."""
+    if reduce_fn is not None and reduce_dev_fn is not None:
+        raise ValueError("give reduce_fn or reduce_dev_fn, not both")
     ctx = ctx or L.default_context()
     yi = L.Images(y)
     B, M, N = yi.B, yi.M, yi.N
@@ -136,6 +142,11 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
             nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))     # column-major images
             nz_ptr = nz_keep.ctypes.data_as(C.c_void_p)
     cb = L.ALLREDUCE_FN(reduce_fn) if reduce_fn is not None else L.ALLREDUCE_FN()
+    xflags = L.SAPG_HOST_LOOP if host_loop else 0
+    if reduce_dev_fn is not None:
+        cb_dev = L.ALLREDUCE_DEV_FN(reduce_dev_fn)            # kept alive until the call returns
+        cb = C.cast(cb_dev, L.ALLREDUCE_FN)
+        xflags |= L.REDUCE_DEVICE
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     yptr = yi.ptr
     if share_gradients:
@@ -151,7 +162,7 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
             xl = L.Images(np.zeros((nch, M, N)))
     ctx.check(ctx.lib.sbtv_SAPG_algorithm(ctx.h, yptr, M, N, nch, C.byref(o), x0i.ptr if x0i else None, nz_ptr,
                                           vp(thetas), vp(ps), vp(sigmas), vp(logpi), vp(logpi_wu), vp(gx), vp(grads),
-                                          vp(eb), xl.ptr, cb, None, yi.flags), yi.flags)
+                                          vp(eb), xl.ptr, cb, None, yi.flags | xflags), yi.flags)
     results = []
     for b in range(nch):
         r = dict(theta_EB=eb[b, 0], sigma_EB=eb[b, 3], last_samp=S, thetas=thetas[b], sigmas=sigmas[b],

@@ -515,3 +515,97 @@ def test_sapg_shared_chains_peer_failure_is_reported_not_waited_for(ctx):
     with pytest.raises(sbtv.SbtvError) as e:
         sbtv.SAPG_algorithm_Guassian(st["y"], dict(op, chains=2), c, share_gradients=True, reduce_fn=reduce_fn)
     assert e.value.code == -14 and len(calls) == 3
+
+
+@pytest.mark.parametrize("kind,fixed", [("gaussian", True), ("gaussian", False), ("moffat", False), ("laplace", False)])
+def test_sapg_device_resident_loop_matches_host_side_loop(ctx, kind, fixed):
+    """The default SAPG loop keeps theta / p / sigma, their gradients, the projected updates, the PSF taps and the traces
+    on the device (sapg_update_kernel: SAPG_algorithm_Guassian.m:165-248 without a host round trip per iteration);
+    `host_loop=True` is the round-1 loop that fetches the scalars every iteration.  Same arithmetic: with fixed PSF
+    parameters every trace is bit-identical; with moving ones the taps come from the device's exp / pow instead of the
+    host's libm (last-bit differences), so the traces agree to rounding."""
+    import sbtv
+    import sbtv_oracle as o
+    M, N = 48, 32
+    x = synth_image(M, N, 9)
+    st = o.demo_setup(kind, x, np.random.default_rng(4).standard_normal((M, N)), evMax=0.99)
+    samples, warmup, burnIn = 14, 5, 6
+    op, c, names = _op_struct(kind, st, samples, warmup, burnIn)
+    op["seed"] = 5
+    for nm in names:
+        op["fix_" + nm] = int(fixed)
+    if kind == "moffat":
+        op["alpha_init"], op["beta_init"] = 0.6, 5.0              # away from the bounds, where the projection would pin them
+    fn = {"gaussian": sbtv.SAPG_algorithm_Guassian, "moffat": sbtv.SAPG_algorithm_moffat,
+          "laplace": sbtv.SAPG_algorithm_laplace}[kind]
+    y2 = np.stack([st["y"], st["y"][::-1].copy()])             # two independent chains / images in one call
+    dev = fn(y2, op, c)[-1]
+    host = fn(y2, op, c, host_loop=True)[-1]
+    keys = ["thetas", "sigmas", "logPiTraceX", "logPiTrace_WU", "gXTrace", "grad_theta", "grad_sigma", "theta_EB",
+            "sigma_EB", "Xlast_sample"] + [nm + "s" for nm in names] + [nm + "_EB" for nm in names]
+    for b in range(2):
+        for key in keys:
+            if fixed:
+                np.testing.assert_array_equal(np.asarray(dev[b][key]), np.asarray(host[b][key]), err_msg=key)
+            else:
+                np.testing.assert_allclose(np.asarray(dev[b][key]), np.asarray(host[b][key]), rtol=1e-9, atol=1e-9,
+                                           err_msg=key)
+        if not fixed:
+            assert any(len(set(np.asarray(dev[b][nm + "s"]).tolist())) > 1 for nm in names)     # a parameter did move
+
+
+def test_sapg_in_stream_device_reduce_two_contexts_match_one_call(ctx):
+    """SBTV_REDUCE_DEVICE: the shared-gradient sums stay in a device buffer and the callback gets that buffer and the
+    library's stream (in production `dist.make_device_allreduce_fn`: an RCCL all-reduce enqueued on that stream, the
+    host never waits).  Here two contexts play two ranks on one GPU and the callback sums their buffers by hand."""
+    import threading
+    import torch
+    import sbtv
+    import sbtv_oracle as o
+    from sbtv.dist import _DeviceView
+    M = N = 32
+    x = synth_image(M, N, 3)
+    st = o.demo_setup("gaussian", x, np.random.default_rng(2).standard_normal((M, N)), evMax=0.99)
+    samples, warmup, burnIn = 10, 4, 5
+    op, c, names = _op_struct("gaussian", st, samples, warmup, burnIn)
+    op["seed"] = 11
+    one = sbtv.SAPG_algorithm_Guassian(st["y"], dict(op, chains=4), c, share_gradients=True)[-1]
+    bar = threading.Barrier(2)
+    slots, results, errors, calls = [None, None], [None, None], [], [0, 0]
+
+    def make_reduce(r):
+        def reduce_dev_fn(user, ptr, n, stream):
+            t = torch.as_tensor(_DeviceView(ptr, n), device="cuda:0")
+            torch.cuda.ExternalStream(stream).synchronize()           # the test sums on the host: wait for phase 1
+            slots[r] = t.cpu().numpy().copy()
+            bar.wait(timeout=60)
+            tot = slots[0] + slots[1]                                 # fixed order: rank 0 + rank 1
+            bar.wait(timeout=60)
+            t.copy_(torch.from_numpy(tot))
+            torch.cuda.synchronize()
+            calls[r] += 1
+            return 0
+        return reduce_dev_fn
+
+    def run(r):
+        try:
+            cx = sbtv.Context(0)
+            results[r] = sbtv.SAPG_algorithm_Guassian(st["y"], dict(op, chains=2, chain_offset=2 * r), c,
+                                                      share_gradients=True, reduce_dev_fn=make_reduce(r), ctx=cx)[-1]
+        except Exception as e:                                        # pragma: no cover
+            errors.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert calls == [samples - 1, samples - 1]
+    two = results[0] + results[1]
+    for k in range(4):
+        np.testing.assert_allclose(two[k]["thetas"], one[k]["thetas"], rtol=1e-12)
+        np.testing.assert_allclose(two[k]["sigmas"], one[k]["sigmas"], rtol=1e-12)
+        np.testing.assert_allclose(two[k]["w1s"], one[k]["w1s"], rtol=1e-12)
+        np.testing.assert_allclose(two[k]["Xlast_sample"], one[k]["Xlast_sample"], rtol=1e-9, atol=1e-9)

@@ -79,6 +79,7 @@ def main():
                                                          "over all ranks; single process default: one GPU's share")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
     ap.add_argument("--backend", default=None)
+    ap.add_argument("--host-reduce", action="store_true", help="config 5: host-callback all-reduce (round-1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true")
     a = ap.parse_args()
     from sbtv import dist as sd
@@ -122,7 +123,15 @@ def main():
     if share:
         op["chains"], op["chain_offset"] = nimg, first
         y = sbtv.to_device(st["y"], dev)
-        kw = dict(share_gradients=True, reduce_fn=sd.make_allreduce_fn(), ctx=ctx)
+        # in-stream RCCL all-reduce on the library's device buffer (the loop never waits for the host);
+        # --host-reduce selects the round-1 host callback (D2H, all-reduce, H2D and a synchronisation per iteration)
+        import torch.distributed as tdist0
+        if world > 1 and tdist0.get_backend() != "nccl":
+            a.host_reduce = True         # gloo stages device tensors through the host anyway: use the host callback
+        if a.host_reduce:
+            kw = dict(share_gradients=True, reduce_fn=sd.make_allreduce_fn(), ctx=ctx)
+        else:
+            kw = dict(share_gradients=True, reduce_dev_fn=sd.make_device_allreduce_fn(local), ctx=ctx)
     else:
         y = sbtv.to_device(np.stack([st["y"]] * nimg), dev)
         kw = dict(ctx=ctx)
@@ -167,8 +176,9 @@ def main():
             "steps": it, "ms_per_iteration": 1e3 * dt / it, "ms_per_local_unit_iteration": 1e3 * dt / it / nimg,
             "higher_is_better": True, "scaling": "weak" if a.total == 0 and world == 1 else "strong",
             "dtype": "f64", "data": "synthetic",
-            "collective": ("all-reduce of 6 doubles per iteration (sbtv.dist.make_allreduce_fn)" if share and world > 1
-                           else "none"),
+            "collective": (("all-reduce of 6 doubles per iteration, " + ("host callback (sbtv.dist.make_allreduce_fn)"
+                            if a.host_reduce else "in-stream on the device buffer (sbtv.dist.make_device_allreduce_fn)"))
+                           if share and world > 1 else "none"),
             "chains_agree_across_ranks": same,
             "config": {"workload": f"SAPG {kind}, chambolleit=25, {total} x {size}^2 {unit}", "image": [size, size],
                        "units_total": total, "units_per_rank": nimg, "parallelism": f"{unit} x{world}"}}), flush=True)
