@@ -48,6 +48,8 @@ constexpr int TW = 1 << TWS;
 __device__ __forceinline__ size_t s_tiled(int k, int l, int n1) {
     return (((size_t)(l >> TWS) * n1 + k) << TWS) + (l & (TW - 1));
 }
+// operator spectra in the same tiling (n1 + 1 rows: k = 0..M/2): a workgroup's 4 rows x 4 columns are 256 contiguous bytes
+__device__ __forceinline__ size_t u_tiled(int k, int l, int n1) { return ((size_t)(l >> TWS) * (n1 + 1) + k) * TW + (l & (TW - 1)); }
 
 template <bool INV>
 __device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int idx) {
@@ -432,6 +434,7 @@ struct RowsParams {
     int shared_spec;        // 1: H / Y / D1 / D2 hold ONE spectrum shared by every image of the batch
     size_t u_img;           // elements of one operator spectrum per image
     int u_ld;               // leading dimension of the row-major operator spectra (tiled mode)
+    int u_tiled;            // operator spectra in the tiled layout U[(l/4)][k][l%4], k = 0..n1
 };
 
 template <int OP>
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     RowsX<RK> X{lds, LDSN, q};
     double2 v[8];
     auto sidx = [&](int l) -> size_t { return TILED ? s_tiled(k, l, n1) : (size_t)l * n1 + k; };
-    auto uidx = [&](int kk, int l) -> size_t { return (size_t)l * (n1 + 1) + kk; };
+    auto uidx = [&](int kk, int l) -> size_t { return (TILED && p.u_tiled) ? u_tiled(kk, l, n1) : (size_t)l * (n1 + 1) + kk; };
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = in[sidx(t + s * T)];
     if (p.fwd) fft_stages<LOG2N, 0, false>(v, t, p.tw, X);
@@ -628,7 +631,7 @@ template <int TT>
 __global__ __launch_bounds__(64) void psf_spectrum_kernel(const double *__restrict__ taps, int taille,
                                                           double2 *__restrict__ U, int n1, int M, int N,
                                                           const double2 *__restrict__ tw_M,
-                                                          const double2 *__restrict__ tw_N, int lch) {
+                                                          const double2 *__restrict__ tw_N, int lch, int tiled) {
     constexpr int TN = TT ? TT : PSF_TMAX;
     const int b = blockIdx.z;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,14 +654,14 @@ __global__ __launch_bounds__(64) void psf_spectrum_kernel(const double *__restri
         }
         c[nn] = cc;
     }
-    double2 *out = U + (size_t)b * (n1 + 1) * N + k;
+    double2 *ub = U + (size_t)b * (n1 + 1) * N;
     const int l0 = blockIdx.y * lch, l1 = min(l0 + lch, N);
     for (int l = l0; l < l1; ++l) {
         double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
         for (int nn = 0; nn < TN; ++nn)
             if (TT || nn < taille) acc = cadd(acc, cmul(c[nn], tw_N[(l * nn) & (N - 1)]));
-        out[(size_t)l * (n1 + 1)] = acc;
+        ub[tiled ? ((size_t)(l >> 2) * (n1 + 1) + k) * 4 + (l & 3) : (size_t)l * (n1 + 1) + k] = acc;
     }
 }
 
@@ -686,6 +689,24 @@ static inline bool rows_wave() {
     }();
     return on;
 }
+// operator spectra tiled like S (default) or column-major U[l][k] (SBTV_U_TILED=0, the round-1 layout) in the wave mode
+static inline bool u_tiled_wanted() {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_U_TILED");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// software-pipelined row pass (rows_pipe_kernel) for the sizes of the wave mode; SBTV_ROWS_PIPE=0: the workgroup row
+// kernel on the tiled layout instead (A/B runs: profiles/r02_rows_pipe.md)
+static inline bool rows_pipe(int log2n) {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_ROWS_PIPE");
+        return !(e && e[0] == '0');
+    }();
+    (void)log2n;
+    return on;
+}
 static inline int rows_v(int dflt) {     // values per thread of the wave-granular row pass (tuning hook: SBTV_ROWS_V=8|16)
     static const int v = [] {
         const char *e = getenv("SBTV_ROWS_V");
@@ -706,6 +727,7 @@ int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
         pl->wave = 0;
         pl->n1 = M;                       // so that 1 / (n1 N) is the inverse scale and S has n1 x N entries
         pl->u_ld = 0;
+        pl->u_tiled = 0;
         pl->s_img = pl->u_img = (size_t)M * N;
         pl->tw_n1 = nullptr;
         SBTV_TRY(twiddle_get(ctx, M, &pl->tw_M));
@@ -719,6 +741,7 @@ int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
     // operator spectra: row-major U[k][l] with a padded leading dimension for the wave-granular row kernel, the
     // column-major U[l][k] (leading dimension M/2 + 1, u_ld = 0) otherwise
     pl->u_ld = (pl->wave && rows_wave()) ? N + 16 : 0;
+    pl->u_tiled = (pl->wave && !rows_wave() && u_tiled_wanted()) ? 1 : 0;
     pl->u_img = pl->u_ld ? (size_t)(pl->n1 + 1) * pl->u_ld : (size_t)(pl->n1 + 1) * N;
     SBTV_TRY(twiddle_get(ctx, pl->n1, &pl->tw_n1));
     SBTV_TRY(twiddle_get(ctx, M, &pl->tw_M));
@@ -897,6 +920,26 @@ static void launch_rows_wave(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams 
     }
 }
 
+template <int L>
+static void launch_rows_pipe(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
+    const dim3 grid(pl.n1 / 4, pl.batch), block((1 << L) / 4);
+#define SBTV_ROWS_OP(OP_)                                                                                     \
+    case OP_: hipLaunchKernelGGL((rows_pipe_kernel<L, OP_>), grid, block, 0, ctx->stream, p); break;
+    switch (p.op) {
+        SBTV_ROWS_OP(OP_NONE)
+        SBTV_ROWS_OP(OP_MUL_H)
+        SBTV_ROWS_OP(OP_MUL_HC)
+        SBTV_ROWS_OP(OP_INVLS)
+        SBTV_ROWS_OP(OP_SALSA)
+        SBTV_ROWS_OP(OP_RESID)
+        SBTV_ROWS_OP(OP_GRAD)
+        SBTV_ROWS_OP(OP_ATA)
+        SBTV_ROWS_OP(OP_GRADF)
+        default: break;
+    }
+#undef SBTV_ROWS_OP
+}
+
 template <int L, int RK, bool TILED = false>
 static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
     const dim3 grid(pl.n1 / RK, pl.batch), block(RK * ((1 << L) / 8));
@@ -936,10 +979,18 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.shared_spec = a.shared_spec;
     p.u_img = pl.u_img;
     p.u_ld = pl.u_ld;
+    p.u_tiled = pl.u_tiled;
     if (pl.generic) return any_rows(ctx, pl, p, Sout);
     const int L = ilog2(pl.N);
     if (L > 12) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 4096");
     if (pl.wave && !rows_wave()) {
+        if (rows_pipe(L)) {
+            // software-pipelined row pass (two row pairs per workgroup, loads in flight across the arithmetic)
+            if (L == 11) launch_rows_pipe<11>(ctx, pl, p);
+            else launch_rows_pipe<10>(ctx, pl, p);
+            SBTV_HIP(ctx, hipGetLastError());
+            return 0;
+        }
         // the workgroup row kernel on the tiled layout: 4 rows x 4 columns = 256 contiguous bytes per access
         if (L == 11) launch_rows<11, 4, true>(ctx, pl, p);
         else launch_rows<10, 4, true>(ctx, pl, p);
@@ -997,7 +1048,7 @@ int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U) 
     }
     if (pl.wave) {
         hipLaunchKernelGGL(spec_unpack_tiled_kernel, dim3((pl.N + 63) / 64, pl.n1 + 1, pl.batch), dim3(64), 0,
-                           ctx->stream, S, U, pl.n1, pl.N, pl.u_ld);
+                           ctx->stream, S, U, pl.n1, pl.N, pl.u_ld, pl.u_tiled);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
@@ -1029,10 +1080,10 @@ int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int t
     const dim3 grid((pl.n1 + 1 + thr - 1) / thr, (pl.N + lch - 1) / lch, pl.batch);
     if (taille == 7)
         hipLaunchKernelGGL(psf_spectrum_kernel<7>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
-                           pl.tw_M, pl.tw_N, lch);
+                           pl.tw_M, pl.tw_N, lch, pl.u_tiled);
     else
         hipLaunchKernelGGL(psf_spectrum_kernel<0>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
-                           pl.tw_M, pl.tw_N, lch);
+                           pl.tw_M, pl.tw_N, lch, pl.u_tiled);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -221,6 +221,7 @@ struct FftPlan {
     int M, N, batch;
     int n1;                 // M/2  (column transform length, complex)
     int wave;               // 1: wave-granular kernels + tiled spectrum layout (fft_wave.inc), chosen by the image size
+    int u_tiled;            // wave mode, workgroup / pipelined row kernels: operator spectra tiled like S, U[(l/4)][k][l%4], k = 0..M/2
     int u_ld;               // wave mode: leading dimension of the row-major operator spectra U[k][l] (N + pad: a
                             // power-of-two row stride would put every workgroup's row on the same memory channels)
     size_t u_img;           // complex elements of ONE operator spectrum (H, Y, D1, D2) per image
