@@ -452,7 +452,8 @@ __device__ __forceinline__ double2 spec_apply(double2 V, double2 H, double2 Y, d
     } else if constexpr (OP == OP_SALSA) {
         const double d = cabs2(H) + mu;
         const double2 num = cadd(cmulc(Y, H), cscale(V, mu));     // conj(H) Y + mu S
-        const double2 Xh = make_double2(num.x / d, num.y / d);
+        const double rd = 1.0 / d;                                // one IEEE reciprocal instead of two divisions
+        const double2 Xh = make_double2(num.x * rd, num.y * rd);
         const double2 R = csub(Y, cmul(H, Xh));
         acc[0] += wgt * cabs2(R);
         return Xh;
