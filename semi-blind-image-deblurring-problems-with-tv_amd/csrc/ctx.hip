@@ -140,7 +140,9 @@ int pinned_get(sbtv_ctx *ctx, size_t bytes, void **out) {
             ctx->pinned_bytes = 0;
         }
         size_t want = (bytes + 4095) & ~size_t(4095);
-        SBTV_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        // coherent (fine-grained): device writes are visible to the host while the stream is still running (the solver
+        // loops poll completion tags in this block)
+        SBTV_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocCoherent));
         ctx->pinned_bytes = want;
     }
     *out = ctx->pinned;

@@ -1,0 +1,25 @@
+#!/bin/bash
+# per-launch kernel durations of a few SALSA iterations in launch order (run on the GPU box): bash tools/trace_seq.sh
+set -eo pipefail
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/trace_seq; rm -rf "$O"
+(cd /tmp; rocprofv3 --kernel-trace --output-format csv -d "$O" -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-batched --no-extras > "$O.log" 2>&1)
+python3 - "$O" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+t0 = int(rows[0]["Start_Timestamp"])
+out = []
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    out.append((r["Kernel_Name"][:42], (s - t0) / 1e3, (e - s) / 1e3))
+# last ~40 launches
+prev_end = None
+for name, s, d in out[-45:]:
+    gap = (s - prev_end) if prev_end is not None else 0.0
+    print("%-42s start %10.1f us  dur %7.2f  gap %6.2f" % (name, s, d, gap))
+    prev_end = s + d
+PY
+rm -rf "$O"
