@@ -12,7 +12,7 @@ P = 2048 * 2048
 MODEL = [   # kernel prefix, what moves, bytes per pixel
     ("chambolle_fused_kernel<4, 8, 4, true>", "read g,px,py + write px,py once per 5-iteration launch (+ f on every 2nd): 44 B/px", 44),
     ("cols_fwd_wave_kernel<10, 16>", "read u, bu; write S: 24 B/px", 24),
-    ("fft_rows_kernel<11, 4, 4, true>", "read S, H, Y; write S: 32 B/px", 32),
+    ("rows_pipe_kernel<11, 4>", "read S, H, Y; write S: 32 B/px", 32),
     ("cols_inv_wave_kernel<10, 16, 3>", "read S, u, bu, true; write x, bu, g: 56 B/px", 56),
 ]
 stats = {r[0]: r for r in csv.reader(open(f"profiles/{tag}_kernel_stats.csv"))}

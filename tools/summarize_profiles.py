@@ -66,7 +66,7 @@ def main():
         sys.path.insert(0, ROOT)
         import bench
         loop = ("chambolle_fused_kernel", "chambolle_pipe_kernel", "chambolle_fused_ctrl_kernel", "fft_cols_fwd_kernel",
-                "cols_fwd_wave_kernel", "fft_rows_kernel", "rows_wave_kernel", "fft_cols_inv_kernel",
+                "cols_fwd_wave_kernel", "fft_rows_kernel", "rows_wave_kernel", "rows_pipe_kernel", "fft_cols_inv_kernel",
                 "cols_inv_wave_kernel", "salsa_collect_kernel")
         n_outer = max(len(per.get(k, [])) for k in per if k.startswith("salsa_collect_kernel"))
         kernels, total = {}, 0.0
