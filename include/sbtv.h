@@ -166,7 +166,13 @@ typedef struct sbtv_salsa_opts {
     int    TViters;          /* 'TVITERS'   default 5 (:181)                        */
     int    initialization;   /* 0 zeros (:369), 2 AT*y (:373), 33333 x_init given   */
     int    compute_mse;      /* 1 when 'TRUE_X' given (:227-229)                    */
-    int    speculate;        /* 0: host checks the stop rule every outer iteration  */
+    int    speculate;        /* bit 0 (default 1): the host evaluates the outer stop rule one iteration late while the
+                              * next iteration already runs (0: it waits for every iteration).
+                              * bit 1: never launch the TV prox optimistically.  By default the Chambolle launches of an
+                              * outer iteration run all TViters iterations without stop-rule kernels and the rule
+                              * (chambolle_prox_TV_stop.m:131) is applied over those steps at the end of the iteration;
+                              * if it fired before the last one the whole solve is repeated with exact launches, so the
+                              * result is always that of the exact rule (TViters <= 10, even M). */
     double tolA;             /* 'TOLERANCEA' default 1e-3 (:178)                    */
     double chambolle_tol;    /* 1e-3  (chambolle_prox_TV_stop.m:78)                 */
     double chambolle_tau;    /* 0.249 (chambolle_prox_TV_stop.m:77)                 */

@@ -22,6 +22,7 @@
 
 namespace sbtv {
 
+constexpr int SALSA_TAGS = 8 + FSMAX;   // completion tags per image: 8 scalars + FSMAX prox step sums
 struct Collect {
     const double *acc;      // rows kernel partials: [batch][3][nrb]           -> resid2
     int nrb;
@@ -29,6 +30,11 @@ struct Collect {
     int ntv;
     const double *post;     // post kernel partials [batch][6][npb]
     int npb;
+    // optimistic prox launches (prox_iterate with spec_cur): error partials [batch][FSMAX][pnblk] of the psteps iterations
+    // the launches ran without a stop rule; block 7 applies the rule afterwards (null: the prox ran exactly)
+    const double *ppart;
+    int pnblk, psteps, pflip;
+    unsigned long long psum_addr;   // [batch][FSMAX] step sums (pinned host memory, as an integer like `out`)
 };
 
 // grid (7, batch): block q reduces ONE quantity of SalsaScal (fixed order, deterministic)
@@ -46,6 +52,37 @@ __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl 
     double *__restrict__ tags = reinterpret_cast<double *>(tags_addr);
     __shared__ double red[4];
     const int b = blockIdx.y, qn = blockIdx.x;
+    if (qn >= 7) {
+        // optimistic prox launches: block 7 + s totals the error partials of Chambolle step s (fixed order) and hands
+        // the sum to the host, which applies the stop rule of chambolle_prox_TV_stop.m:131 over the steps itself
+        const int st = qn - 7;
+        const double *pp = c.ppart + ((size_t)b * FSMAX + st) * c.pnblk;
+        double acc = 0.0;
+        constexpr int NB = 8;
+        for (int base = 0; base < c.pnblk; base += 256 * NB) {
+            double v[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int q = base + r * 256 + (int)threadIdx.x;
+                v[r] = (q < c.pnblk) ? __hip_atomic_load(pp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) acc += v[r];
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double *steps = reinterpret_cast<double *>(c.psum_addr);
+            steps[(size_t)b * FSMAX + st] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (tags_addr) {
+                __threadfence_system();
+                __hip_atomic_store(&reinterpret_cast<double *>(tags_addr)[(size_t)b * SALSA_TAGS + 8 + st], seq,
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     const double *p = nullptr;
     int n = 0;
     if (qn == 0) {
@@ -73,10 +110,11 @@ __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl 
         double *o = reinterpret_cast<double *>(&out[b]);      // SalsaScal is 8 doubles in this order
         o[qn] = (red[0] + red[1]) + (red[2] + red[3]);
         if (qn == 0) {
-            o[7] = ctrl ? (double)ctrl[b].k : 0.0;            // Chambolle iterations actually run
+            o[7] = ctrl ? (double)ctrl[b].k : 0.0;            // Chambolle iterations booked by exact launches
             if (ctrl && rearm) {
                 ProxCtrl pc = ctrl[b];
                 pc.k = 0;
+                if (c.ppart && (c.pflip & 1)) pc.cur = (pc.cur & 1) ^ 1;   // optimistic prox with an odd number of launches
                 pc.done = (frozen && frozen[b]) ? 1 : 0;
                 pc.redo = 0;
                 pc.f_valid = 0;
@@ -88,8 +126,8 @@ __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl 
             // completion tag of this scalar (pinned, coherent host memory): the host polls the tags instead of waiting
             // for an event - an event record costs the stream 5-6 us of idle time per outer iteration
             __threadfence_system();
-            __hip_atomic_store(&tags[(size_t)b * 8 + qn], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (qn == 0) __hip_atomic_store(&tags[(size_t)b * 8 + 7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&tags[(size_t)b * SALSA_TAGS + qn], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (qn == 0) __hip_atomic_store(&tags[(size_t)b * SALSA_TAGS + 7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -137,7 +175,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const int maxiter = opts->maxiter;
     const bool want_mse = (true_x != nullptr);
     const bool crit2 = (opts->stopcriterion == 2);
-    const int lag = opts->speculate ? 1 : 0;
+    const int lag = (opts->speculate & 1) ? 1 : 0;
+    const long long calls_at_entry = ctx->calls;
 
     // ---- stage inputs
     const double *yd = nullptr, *td = nullptr, *xi = nullptr;
@@ -184,19 +223,22 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     int *frozen_h = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 4 * batch + sizeof(int) * batch, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 2 * batch + sizeof(double) * 2 * batch * (FSMAX + SALSA_TAGS) + sizeof(int) * batch, &pz));
         scal_h = static_cast<SalsaScal *>(pz);
         void *dp = nullptr;
         SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
         scal_hd = static_cast<SalsaScal *>(dp);
-        frozen_h = reinterpret_cast<int *>(scal_h + 4 * (size_t)batch);
+        frozen_h = reinterpret_cast<int *>(reinterpret_cast<double *>(scal_h + 2 * (size_t)batch) + 2 * (size_t)batch * (FSMAX + SALSA_TAGS));
         for (int b = 0; b < batch; ++b) frozen_h[b] = 0;
     }
     // completion tags [2][batch][8] behind the scalars (same pinned block): tag q of slot s = outer iteration whose
     // scalar q is in scal_h[s]
-    double *tags_h = reinterpret_cast<double *>(scal_h + 2 * (size_t)batch);
-    double *tags_hd = reinterpret_cast<double *>(scal_hd + 2 * (size_t)batch);
-    for (size_t i = 0; i < (size_t)2 * batch * 8; ++i) tags_h[i] = 0.0;
+    // behind them: the prox step sums [2][batch][FSMAX] of the optimistic launches
+    double *psum_h = reinterpret_cast<double *>(scal_h + 2 * (size_t)batch);
+    double *psum_hd = reinterpret_cast<double *>(scal_hd + 2 * (size_t)batch);
+    double *tags_h = psum_h + 2 * (size_t)batch * FSMAX;
+    double *tags_hd = psum_hd + 2 * (size_t)batch * FSMAX;
+    for (size_t i = 0; i < (size_t)2 * batch * SALSA_TAGS; ++i) tags_h[i] = 0.0;
     const double inv_scale = 1.0 / ((double)fp.n1 * N);
     const double parseval = 1.0 / ((double)M * N);
 
@@ -255,7 +297,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         double *o4 = nullptr;
         SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
         if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
-        Collect c{acc, nrb, tvp, ntv, nullptr, 0};
+        Collect c{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0, 0ull};
         hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (ProxCtrl *)nullptr,
                            (unsigned long long)(uintptr_t)scal_d, (const int *)nullptr, 0, 0ull, 0.0);
         SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
@@ -303,11 +345,20 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // enqueue the kernels of outer iteration `outer` (reads x = xbuf[(outer-1)&1] through g, writes
     // xbuf[outer&1]); `timed` brackets the prox with events (not inside a graph capture)
     bool prox_timed[2] = {false, false};
-    bool slot_tagged[2] = {false, false};
+    // Optimistic prox launches: the Chambolle launches of an outer iteration run all TViters iterations without
+    // stop-rule kernels and without the redo pass (three launches less per outer iteration); the collector applies the
+    // rule over all steps at the end of the iteration.  Natural images never meet err <= tol inside a prox
+    // (SURVEY.md section 8 a-1); if one does, the solve is repeated from the start with exact launches (bit 1 of
+    // `speculate`), so the result is always that of the exact rule.
+    // The first outer iteration always runs exactly: from the zero start its prox input is flat and the rule stops at k = 1.
+    const bool spec_ok = !(opts->speculate & 2) && !graph_wanted(cnt) && prox_spec_ok(pp, g, u, opts->TViters);
+    bool fired_early = false;
+    bool slot_tagged[2] = {false, false}, slot_spec[2] = {false, false};
     long long prox_iters_timed = 0;
     auto enqueue_body = [&](int outer, bool eager) -> int {
         const int slot = outer & 1;
         const bool tagged = eager;
+        const bool spec = spec_ok && outer >= 2;
         // the prox is bracketed by events on every 16th iteration only: an event record leaves the stream idle for
         // 5-6 us; sbtv_last_timing scales the sampled time to all iterations
         const bool timed = eager && ((outer & 15) == 1);
@@ -317,7 +368,9 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         // (1) TV prox with warm-started duals (:429); the control block was re-armed by the previous
         //     iteration's collector (or by prox_reset before the loop)
         if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
-        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u));     // u = g - lambda div p written by the last launch
+        // u = g - lambda div p written by the last launch.  Optimistic mode: no stop-rule kernels, no redo pass; the
+        // collector applies the rule over all TViters steps at the end of the iteration
+        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u, false, spec));
         if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
         prox_timed[slot] = timed;
         // (2) LS step in the spectral domain + residual energy (:434-444)
@@ -342,14 +395,16 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         cp.xprev = crit2 ? xprev : nullptr;
         cp.partials = postp;
         SBTV_TRY(fft_cols_inv_post(ctx, fp, S, xn, inv_scale, frozen_d, cp));
-        Collect c{acc, nrb, nullptr, 0, postp, npb};
+        Collect c{acc, nrb, nullptr, 0, postp, npb, spec ? pp.partials : nullptr, pp.fnblk, opts->TViters,
+                  prox_launches(pp, opts->TViters), (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSMAX)};
         // the collector writes the eight scalars straight into pinned host memory (no copy kernel);
         // they are visible to the host once ev_done has completed
         // eager launches: the collector tags its scalars with the iteration number (the host polls the tags);
         // inside a captured graph the arguments are frozen, so replay keeps the event
-        hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, pp.ctrl,
+        slot_spec[slot] = spec;
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(spec ? 7 + opts->TViters : 7, batch), dim3(256), 0, ctx->stream, c, pp.ctrl,
                            (unsigned long long)(uintptr_t)(scal_hd + (size_t)slot * batch), (const int *)frozen_d, 1,
-                           tagged ? (unsigned long long)(uintptr_t)(tags_hd + (size_t)slot * batch * 8) : 0ull, (double)outer);
+                           tagged ? (unsigned long long)(uintptr_t)(tags_hd + (size_t)slot * batch * SALSA_TAGS) : 0ull, (double)outer);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
@@ -379,12 +434,14 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // stream query makes the runtime append a marker packet, which costs the stream 5-6 us before the next kernel.
     // Only after 50 ms without the tags is the stream asked, so that a failed launch cannot leave the host waiting.
     auto wait_tags = [&](int slot, int outer) -> int {
-        volatile const double *tg = tags_h + (size_t)slot * batch * 8;
+        volatile const double *tg = tags_h + (size_t)slot * batch * SALSA_TAGS;
         const double want = (double)outer;
+        const int ntag = 8 + (slot_spec[slot] ? opts->TViters : 0);
         auto t_begin = std::chrono::steady_clock::now();
         for (unsigned spin = 0;; ++spin) {
             bool ready = true;
-            for (size_t i = 0; i < (size_t)batch * 8 && ready; ++i) ready = (tg[i] == want);
+            for (int b = 0; b < batch && ready; ++b)
+                for (int i = 0; i < ntag && ready; ++i) ready = (tg[(size_t)b * SALSA_TAGS + i] == want);
             if (ready) break;
             if (spin < 200) {
                 __builtin_ia32_pause();
@@ -416,7 +473,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             SBTV_HIP(ctx, hipEventElapsedTime(&ms, ev_p0[slot], ev_p1[slot]));
             ms_prox += ms;
             for (int b = 0; b < batch; ++b)
-                if (!frozen[b]) prox_iters_timed += (long long)scal_h[(size_t)slot * batch + b].pad;
+                if (!frozen[b]) prox_iters_timed += slot_spec[slot] ? (long long)opts->TViters : (long long)scal_h[(size_t)slot * batch + b].pad;
             prox_timed[slot] = false;
         }
         const double tnow = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -426,7 +483,19 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             const SalsaScal &s = scal_h[(size_t)slot * batch + b];
             h_numA[b] += 1;
             h_nouter[b] = outer;
-            prox_iters_run += (long long)s.pad;
+            double prox_k = s.pad;                   // exact launches: iterations booked by the stop-rule kernels
+            if (slot_spec[slot]) {
+                // optimistic launches: cont = (k < MaxIter) & (err > tol)  (chambolle_prox_TV_stop.m:131) over the steps
+                const double *ps = psum_h + ((size_t)slot * batch + b) * FSMAX;
+                prox_k = (double)opts->TViters;
+                for (int k = 1; k < opts->TViters; ++k)
+                    if (!(sqrt(ps[k - 1]) > opts->chambolle_tol)) {
+                        fired_early = true;          // the rule stopped before the last step: start over, exactly
+                        break;
+                    }
+                if (fired_early) break;
+            }
+            prox_iters_run += (long long)prox_k;
             ctx->calls += 2;   // invLS + A (callcounter)
             const double f = 0.5 * (s.resid2 * parseval) + tau[b] * s.tv_u;                  // :444
             if (objective) objective[(size_t)b * (maxiter + 1) + outer] = f;
@@ -452,6 +521,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                 changed = true;
             }
         }
+        if (fired_early) return 0;
         if (changed && active > 0)
             SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen_h, sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
         return 0;
@@ -463,11 +533,19 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         while (rc == 0 && enq < maxiter && enq - done <= lag && active > 0) rc = enqueue(++enq);
         if (rc != 0) break;
         rc = process(++done);
-        if (rc != 0) break;
+        if (rc != 0 || fired_early) break;
     }
     if (rc != 0) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
+    }
+    if (fired_early) {
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->calls = calls_at_entry;
+        sbtv_salsa_opts exact = *opts;
+        exact.speculate = (opts->speculate & 1) | 2;
+        return sbtv_SALSA_v2(ctx, y, M, N, batch, taps, taille, tau, mu, &exact, true_x, x_init, x_out, objective, distance,
+                             times, mses, numA, numAt, n_outer, flags);
     }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -196,8 +196,11 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);  
 // If f_out is given it receives f = g - lambda div p (fused into the last launch where possible).
 // cold = true: start from px = py = 0 without reading (or requiring the caller to clear) the dual buffer; the
 // control block must have been reset with keep_cur = false.
+constexpr int FSMAX = 10;   // most iterations any fused Chambolle kernel runs per launch (stride of the error partials [batch][FSMAX][nblk])
 int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr,
-                 bool cold = false);
+                 bool cold = false, bool spec = false);
+int prox_launches(const ProxPlan &pl, int maxiter);
+bool prox_spec_ok(const ProxPlan &pl, const double *g, const double *f_out, int maxiter);
 // f = g - lambda * div(p)
 int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
 // periodic TV norm of x -> out_dev[batch] (device)

@@ -219,8 +219,7 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
 // identical to one-iteration-at-a-time execution.
 // ---------------------------------------------------------------------------
 constexpr int FH = 6;                    // halo = max fused iterations of the TILE kernels
-constexpr int FSMAX = 10;                // most iterations ANY fused kernel runs per launch (pipeline kernel: 10):
-                                         // stride of the per-step error partials and size of the control arrays
+// (FSMAX, the step capacity of the error partials, is defined in sbtv_internal.h: the SALSA collector reads them too)
 constexpr int FHJ = 5;                   // right column halo = max steps per launch (rows need an even halo: FH)
 constexpr int FHL = FHJ + 1;             // left column halo: one more, because f = g - lambda div p written by the
                                          // last launch needs py(i, j-1) of the FINAL iterate left of the core
@@ -363,6 +362,33 @@ __global__ __launch_bounds__(64 * FSMAX) void chambolle_fused_ctrl_kernel(ProxCt
     const int b = blockIdx.x;
     ProxCtrl *c = &ctrl[b];
     __shared__ double tots[FSMAX];
+    __shared__ double part[FSMAX];
+    // This kernel is a chain of dependent memory round trips (control block, partials, control block), each ~1 us
+    // from another XCD's write-through data.  The partial sums of all `steps_arg` possible steps are therefore requested
+    // at once and BEFORE the control block is looked at: FSMAX waves, wave w takes step w % steps_arg and the
+    // (w / steps_arg)-th share of its nblk partials, every lane's loads in one batch.
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int smax = redo_mode ? FSMAX : max(1, min(steps_arg, FSMAX));
+    const int shares = FSMAX / smax;                   // waves per step (>= 1)
+    const int st = w % smax, sh = w / smax;
+    double acc = 0.0;
+    if (sh < shares) {
+        const double *p = partials + ((size_t)b * FSMAX + st) * nblk;
+        const int per = (nblk + shares - 1) / shares, q0 = sh * per, q1 = min(nblk, q0 + per);
+        constexpr int NB = 32;                          // up to 32 loads per lane in flight (nblk <= 2048 x shares)
+        for (int base = q0; base < q1; base += 64 * NB) {
+            double v[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int q = base + r * 64 + lane;
+                // agent-scope relaxed atomic load = `global_load ... sc1`: never served from a stale L1 line
+                v[r] = (q < q1) ? __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) acc += v[r];
+        }
+        acc = wave_sum(acc);
+    }
     int nsteps;
     if (redo_mode) {
         if (c->redo <= 0) {
@@ -375,7 +401,14 @@ __global__ __launch_bounds__(64 * FSMAX) void chambolle_fused_ctrl_kernel(ProxCt
         nsteps = min(steps_arg, c->maxiter - c->k);
         if (nsteps <= 0) return;
     }
-    fused_reduce_steps(partials + (size_t)b * FSMAX * nblk, nblk, nsteps, tots);
+    if (lane == 0) part[w] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < nsteps) {
+        double t = 0.0;
+        for (int h = 0; h < shares; ++h) t += part[h * smax + threadIdx.x];     // fixed order
+        tots[threadIdx.x] = t;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         if (redo_mode) {
             c->k += nsteps;
@@ -656,10 +689,35 @@ int g_force_single_step = 0;   // test hook (SBTV_SINGLE_STEP=1): one-iteration 
 
 int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
 
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold) {
+// Can prox_iterate run optimistically (spec_cur != nullptr) for this plan and these buffers?  Needs the tile kernels
+// (even M, aligned buffers, not the single-step / pipeline variants) and all steps in the partials' FSMAX slots.
+bool prox_spec_ok(const ProxPlan &pl, const double *g, const double *f_out, int maxiter) {
+    static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
+    static const bool env_off = [] {
+        const char *e = getenv("SBTV_PROX_SPEC");
+        return e && e[0] == '0';
+    }();
+    return !env_off && !env_single && !g_force_single_step && !pl.pipe && maxiter <= FSMAX && vec_ok(g, pl.M) &&
+           vec_ok(pl.pbuf, pl.M) && (!f_out || vec_ok(f_out, pl.M));
+}
+
+// number of fused launches prox_iterate makes for `maxiter` iterations (without the redo pass)
+int prox_launches(const ProxPlan &pl, int maxiter) {
+    const int per_launch = pl.pipe ? PK : FHJ;
+    return (maxiter + per_launch - 1) / per_launch;
+}
+
+// spec: optimistic mode for solver loops (see the kernels, bit 2 of their flag word): the launches run all `maxiter`
+// iterations back to back, launch l from dual buffer cur ^ (l & 1), WITHOUT stop-rule kernels and without the redo
+// pass; the error partials of step s land in slot s and the control blocks are left untouched.  The caller evaluates
+// the rule over the maxiter steps, flips `cur` when prox_launches() is odd, and re-runs exactly if the rule fired early.
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold, bool spec) {
+    const bool spec_cur = spec;
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
     const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
     static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
+    if (spec_cur && !prox_spec_ok(pl, g, f_out, maxiter))
+        return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: optimistic mode is not available for this plan");
     if (v && !env_single && !g_force_single_step && (!f_out || vec_ok(f_out, pl.M))) {
         // temporally fused path: ceil(K/FH) launches of (nearly) equal step counts + the redo pair
         const dim3 fgrid(pl.fnblk, 1, pl.batch);   // linear tile list, remapped per XCD inside the kernel
@@ -673,10 +731,16 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         // switches it off).
         static const char *env_inl = getenv("SBTV_INLINE_CTRL");
         const bool env_inline = env_inl ? (env_inl[0] != '0') : ((size_t)pl.fnblk * pl.batch <= 512);
+        int spec_off = 0, spec_l = 0;                           // steps / launches already made (optimistic mode)
         auto launch_fused = [&](int steps, int redo, int write_f) -> int {
             bool launched = false;
-            const int inl = (!redo && env_inline) ? 1 : 0;
-            const int kflags = inl | (cold ? 2 : 0);            // bit 0: in-kernel stop rule, bit 1: cold start
+            const int inl = (!redo && env_inline && !spec_cur) ? 1 : 0;
+            int kflags = inl | (cold ? 2 : 0);                  // bit 0: in-kernel stop rule, bit 1: cold start
+            if (spec_cur) {                                      // bit 2 + source / destination buffer + first step slot
+                kflags = 4 | ((spec_l & 1) << 8) | (spec_off << 12);
+                ++spec_l;
+                spec_off += steps;
+            }
             if (pl.pipe) {
                 launched = true;
                 if (g_fused.fast)
@@ -741,14 +805,14 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             if (!launched)
                 return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: no fused Chambolle kernel is compiled for this tile geometry");
             // the re-run launch books its own result (last-workgroup ticket; nothing at all when it is empty)
-            if (!inl && !redo)
+            if (!inl && !redo && !spec_cur)
                 hipLaunchKernelGGL(chambolle_fused_ctrl_kernel, dim3(pl.batch), dim3(64 * FSMAX), 0, ctx->stream,
                                    pl.ctrl, pl.partials, pl.fnblk, steps, redo, write_f);
             return 0;
         };
         const int wf = f_out ? 1 : 0;
         for (int l = 0; l < nl; ++l) SBTV_TRY(launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0));
-        SBTV_TRY(launch_fused(0, 1, wf));     // redo pass; doubles as the finish-only pass when f is not valid yet
+        if (!spec_cur) SBTV_TRY(launch_fused(0, 1, wf));     // redo pass; doubles as the finish-only pass when f is not valid yet
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }

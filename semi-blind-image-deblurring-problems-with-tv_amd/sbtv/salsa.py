@@ -11,7 +11,7 @@ from .operators import BlurOperator, _Adjoint, _InvLS
 from .tv import _parse_varargin
 
 _OPTIONS = {"P", "PT", "PSI", "PHI", "TVINITIALIZATION", "TVITERS", "MU", "STOPCRITERION", "TOLERANCEA",
-            "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS", "SEED"}
+            "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS", "SEED", "SPECULATE"}
 
 
 def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
@@ -78,6 +78,8 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
     so.maxiter = int(opts.get("MAXITERA", 10000))
     so.TViters = int(opts.get("TVITERS", 5))
     so.tolA = float(opts.get("TOLERANCEA", 0.001))
+    # extension (no counterpart in the reference): sbtv_salsa_opts.speculate, bit 0 host-side lag, bit 1 exact prox launches
+    so.speculate = int(opts.get("SPECULATE", so.speculate))
     yi = L.Images(y)
     B, M, N = yi.B, yi.M, yi.N
     init = opts.get("INITIALIZATION", 0)

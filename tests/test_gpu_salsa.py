@@ -287,3 +287,56 @@ def test_salsa_takes_the_demos_plain_function_handles(ctx, cman256):
     assert e.value.code == -10
     with pytest.raises(sbtv.SbtvError):                               # handles missing altogether (SALSA_v2.m:262,296)
         sbtv.SALSA_v2(st["y"], A, tau, "MU", mu, "LS", invLS, *args)
+
+
+def test_salsa_optimistic_prox_launches_equal_exact_launches(ctx, man512):
+    """By default the Chambolle launches of an outer iteration run all TViters iterations without stop-rule kernels
+    and the rule is applied afterwards by the collector (three launches less per outer iteration); 'SPECULATE' bit 1
+    forces the exact launches (stop-rule kernel after every launch + redo pass).  The rule never fires inside a prox of
+    a natural image, so both must give the same bits, for 5 (one launch) and 10 (two launches) TV iterations, with and
+    without the host-side lag."""
+    import sbtv
+    x = man512[:256, :256]
+    st = sbtv.demo_setup("gaussian", x, np.random.default_rng(3).standard_normal(x.shape), evMax=1.0)
+    A = sbtv.BlurOperator(sbtv.psf_family("gaussian", 7, (0.4, 0.3))[0])
+    mu = 0.003
+    for tv, crit in ((10, 1), (5, 2), (7, 1)):
+        outs = []
+        for spec in (1, 3, 0, 2):
+            outs.append(sbtv.SALSA_v2(st["y"], A, 0.03 * st["sigma"] ** 2, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", x,
+                                      "StopCriterion", crit, "ToleranceA", 1e-4, "MAXITERA", 25, "TVINITIALIZATION", 1,
+                                      "TViters", tv, "SPECULATE", spec))
+        for o in outs[1:]:
+            np.testing.assert_array_equal(np.asarray(o[0]), np.asarray(outs[0][0]))
+            np.testing.assert_array_equal(np.asarray(o[3]), np.asarray(outs[0][3]))
+            np.testing.assert_array_equal(np.asarray(o[4]), np.asarray(outs[0][4]))
+            np.testing.assert_array_equal(np.asarray(o[6]), np.asarray(outs[0][6]))
+
+
+def test_salsa_stop_rule_firing_inside_the_prox_restarts_exactly(ctx):
+    """A flat observation: u = div p - g/lambda is constant, so err = 0 <= tol and chambolle_prox_TV_stop.m:131 stops at
+    k = 1 in every outer iteration.  The optimistic launches over-run, the collector reports it and the solve is
+    repeated with exact launches: the result must be the oracle's (which applies the rule after every iteration)."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 64
+    y = np.full((M, N), 120.0)
+    y[10:20, 30:40] += 1e-9                       # not exactly flat: err tiny but non-zero
+    model = o.BlurModel("gaussian", (M, N))
+    p = (0.4, 0.3)
+    mu, tau = 0.003, 0.3
+    filt = 1.0 / (np.abs(model.H_FFT(*p)) ** 2 + mu)
+    invLS = lambda v: np.real(o.ifft2(filt * o.fft2(v)))
+    ref = o.SALSA_v2(y, lambda v: model.A(v, *p), tau, mu=mu, AT=lambda v: model.AT(v, *p), invLS=invLS,
+                     stopcriterion=1, tolA=1e-30, maxiter=6, TViters=10)
+    A = sbtv.BlurOperator(model.taps(*p))
+    for spec in (1, 3):
+        got = sbtv.SALSA_v2(y, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "StopCriterion", 1, "ToleranceA", 1e-30,
+                            "MAXITERA", 6, "TVINITIALIZATION", 1, "TViters", 10, "SPECULATE", spec)
+        assert len(got[3]) == len(ref["objective"])
+        np.testing.assert_allclose(np.asarray(got[0]), ref["x"], rtol=1e-10, atol=1e-8)
+        # (the objective falls from 3e7 to 2e-7: below 1e-14 of its start it is rounding noise of the residual sums)
+        np.testing.assert_allclose(np.asarray(got[3]), ref["objective"], rtol=1e-8, atol=1e-14 * ref["objective"][0])
+    # the prox did stop early in the exact run: fewer Chambolle iterations than 6 x 10
+    import sbtv._lib as L
+    assert L.default_context().last_timing()["chambolle_launches"] < 6 * 10
