@@ -22,7 +22,7 @@
 
 namespace sbtv {
 
-constexpr int SALSA_TAGS = 8 + FSMAX;   // completion tags per image: 8 scalars + FSMAX prox step sums
+constexpr int SALSA_TAGS = 8 + FSTRIDE;   // completion tags per image: 8 scalars + FSTRIDE prox step sums
 struct Collect {
     const double *acc;      // rows kernel partials: [batch][3][nrb]           -> resid2
     int nrb;
@@ -30,11 +30,11 @@ struct Collect {
     int ntv;
     const double *post;     // post kernel partials [batch][6][npb]
     int npb;
-    // optimistic prox launches (prox_iterate with spec_cur): error partials [batch][FSMAX][pnblk] of the psteps iterations
+    // optimistic prox launches (prox_iterate with spec_cur): error partials [batch][FSTRIDE][pnblk] of the psteps iterations
     // the launches ran without a stop rule; block 7 applies the rule afterwards (null: the prox ran exactly)
     const double *ppart;
     int pnblk, psteps, pflip;
-    unsigned long long psum_addr;   // [batch][FSMAX] step sums (pinned host memory, as an integer like `out`)
+    unsigned long long psum_addr;   // [batch][FSTRIDE] step sums (pinned host memory, as an integer like `out`)
 };
 
 // grid (7, batch): block q reduces ONE quantity of SalsaScal (fixed order, deterministic)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl 
         // optimistic prox launches: block 7 + s totals the error partials of Chambolle step s (fixed order) and hands
         // the sum to the host, which applies the stop rule of chambolle_prox_TV_stop.m:131 over the steps itself
         const int st = qn - 7;
-        const double *pp = c.ppart + ((size_t)b * FSMAX + st) * c.pnblk;
+        const double *pp = c.ppart + ((size_t)b * FSTRIDE + st) * c.pnblk;
         double acc = 0.0;
         constexpr int NB = 8;
         for (int base = 0; base < c.pnblk; base += 256 * NB) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl 
         __syncthreads();
         if (threadIdx.x == 0) {
             double *steps = reinterpret_cast<double *>(c.psum_addr);
-            steps[(size_t)b * FSMAX + st] = (red[0] + red[1]) + (red[2] + red[3]);
+            steps[(size_t)b * FSTRIDE + st] = (red[0] + red[1]) + (red[2] + red[3]);
             if (tags_addr) {
                 __threadfence_system();
                 __hip_atomic_store(&reinterpret_cast<double *>(tags_addr)[(size_t)b * SALSA_TAGS + 8 + st], seq,
@@ -223,21 +223,21 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     int *frozen_h = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 2 * batch + sizeof(double) * 2 * batch * (FSMAX + SALSA_TAGS) + sizeof(int) * batch, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 2 * batch + sizeof(double) * 2 * batch * (FSTRIDE + SALSA_TAGS) + sizeof(int) * batch, &pz));
         scal_h = static_cast<SalsaScal *>(pz);
         void *dp = nullptr;
         SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
         scal_hd = static_cast<SalsaScal *>(dp);
-        frozen_h = reinterpret_cast<int *>(reinterpret_cast<double *>(scal_h + 2 * (size_t)batch) + 2 * (size_t)batch * (FSMAX + SALSA_TAGS));
+        frozen_h = reinterpret_cast<int *>(reinterpret_cast<double *>(scal_h + 2 * (size_t)batch) + 2 * (size_t)batch * (FSTRIDE + SALSA_TAGS));
         for (int b = 0; b < batch; ++b) frozen_h[b] = 0;
     }
     // completion tags [2][batch][8] behind the scalars (same pinned block): tag q of slot s = outer iteration whose
     // scalar q is in scal_h[s]
-    // behind them: the prox step sums [2][batch][FSMAX] of the optimistic launches
+    // behind them: the prox step sums [2][batch][FSTRIDE] of the optimistic launches
     double *psum_h = reinterpret_cast<double *>(scal_h + 2 * (size_t)batch);
     double *psum_hd = reinterpret_cast<double *>(scal_hd + 2 * (size_t)batch);
-    double *tags_h = psum_h + 2 * (size_t)batch * FSMAX;
-    double *tags_hd = psum_hd + 2 * (size_t)batch * FSMAX;
+    double *tags_h = psum_h + 2 * (size_t)batch * FSTRIDE;
+    double *tags_hd = psum_hd + 2 * (size_t)batch * FSTRIDE;
     for (size_t i = 0; i < (size_t)2 * batch * SALSA_TAGS; ++i) tags_h[i] = 0.0;
     const double inv_scale = 1.0 / ((double)fp.n1 * N);
     const double parseval = 1.0 / ((double)M * N);
@@ -396,7 +396,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         cp.partials = postp;
         SBTV_TRY(fft_cols_inv_post(ctx, fp, S, xn, inv_scale, frozen_d, cp));
         Collect c{acc, nrb, nullptr, 0, postp, npb, spec ? pp.partials : nullptr, pp.fnblk, opts->TViters,
-                  prox_launches(pp, opts->TViters), (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSMAX)};
+                  prox_launches(pp, opts->TViters), (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSTRIDE)};
         // the collector writes the eight scalars straight into pinned host memory (no copy kernel);
         // they are visible to the host once ev_done has completed
         // eager launches: the collector tags its scalars with the iteration number (the host polls the tags);
@@ -486,7 +486,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             double prox_k = s.pad;                   // exact launches: iterations booked by the stop-rule kernels
             if (slot_spec[slot]) {
                 // optimistic launches: cont = (k < MaxIter) & (err > tol)  (chambolle_prox_TV_stop.m:131) over the steps
-                const double *ps = psum_h + ((size_t)slot * batch + b) * FSMAX;
+                const double *ps = psum_h + ((size_t)slot * batch + b) * FSTRIDE;
                 prox_k = (double)opts->TViters;
                 for (int k = 1; k < opts->TViters; ++k)
                     if (!(sqrt(ps[k - 1]) > opts->chambolle_tol)) {

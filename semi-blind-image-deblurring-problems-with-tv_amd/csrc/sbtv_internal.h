@@ -196,7 +196,8 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);  
 // If f_out is given it receives f = g - lambda div p (fused into the last launch where possible).
 // cold = true: start from px = py = 0 without reading (or requiring the caller to clear) the dual buffer; the
 // control block must have been reset with keep_cur = false.
-constexpr int FSMAX = 10;   // most iterations any fused Chambolle kernel runs per launch (stride of the error partials [batch][FSMAX][nblk])
+constexpr int FSMAX = 10;     // most iterations any fused Chambolle kernel runs per LAUNCH
+constexpr int FSTRIDE = 32;   // step slots of the error partials [batch][FSTRIDE][nblk]: most iterations of an optimistic prox
 int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr,
                  bool cold = false, bool spec = false);
 int prox_launches(const ProxPlan &pl, int maxiter);

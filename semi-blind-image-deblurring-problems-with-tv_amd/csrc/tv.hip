@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * FSMAX) void chambolle_fused_ctrl_kernel(ProxCt
     const int st = w % smax, sh = w / smax;
     double acc = 0.0;
     if (sh < shares) {
-        const double *p = partials + ((size_t)b * FSMAX + st) * nblk;
+        const double *p = partials + ((size_t)b * FSTRIDE + st) * nblk;
         const int per = (nblk + shares - 1) / shares, q0 = sh * per, q1 = min(nblk, q0 + per);
         constexpr int NB = 32;                          // up to 32 loads per lane in flight (nblk <= 2048 x shares)
         for (int base = q0; base < q1; base += 64 * NB) {
@@ -643,7 +643,7 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     }
     const size_t P = (size_t)M * N;
     size_t npart = (size_t)batch * pl->nblk;
-    if ((size_t)batch * FSMAX * pl->fnblk > npart) npart = (size_t)batch * FSMAX * pl->fnblk;
+    if ((size_t)batch * FSTRIDE * pl->fnblk > npart) npart = (size_t)batch * FSTRIDE * pl->fnblk;
     const std::string t(tag ? tag : "prox");          // a second concurrent prox (CoRAL) needs its own state
     SBTV_TRY(ws_get_t(ctx, (t + ".ctrl").c_str(), (size_t)batch, &pl->ctrl));
     SBTV_TRY(ws_get_t(ctx, (t + ".pbuf").c_str(), 4 * P * batch, &pl->pbuf));
@@ -690,14 +690,14 @@ int g_force_single_step = 0;   // test hook (SBTV_SINGLE_STEP=1): one-iteration 
 int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f);
 
 // Can prox_iterate run optimistically (spec_cur != nullptr) for this plan and these buffers?  Needs the tile kernels
-// (even M, aligned buffers, not the single-step / pipeline variants) and all steps in the partials' FSMAX slots.
+// (even M, aligned buffers, not the single-step / pipeline variants) and all steps in the partials' FSTRIDE slots.
 bool prox_spec_ok(const ProxPlan &pl, const double *g, const double *f_out, int maxiter) {
     static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
     static const bool env_off = [] {
         const char *e = getenv("SBTV_PROX_SPEC");
         return e && e[0] == '0';
     }();
-    return !env_off && !env_single && !g_force_single_step && !pl.pipe && maxiter <= FSMAX && vec_ok(g, pl.M) &&
+    return !env_off && !env_single && !g_force_single_step && !pl.pipe && maxiter <= FSTRIDE && vec_ok(g, pl.M) &&
            vec_ok(pl.pbuf, pl.M) && (!f_out || vec_ok(f_out, pl.M));
 }
 
@@ -737,7 +737,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             const int inl = (!redo && env_inline && !spec_cur) ? 1 : 0;
             int kflags = inl | (cold ? 2 : 0);                  // bit 0: in-kernel stop rule, bit 1: cold start
             if (spec_cur) {                                      // bit 2 + source / destination buffer + first step slot
-                kflags = 4 | ((spec_l & 1) << 8) | (spec_off << 12);
+                kflags = 4 | (cold ? 2 : 0) | ((spec_l & 1) << 8) | (spec_off << 12);
                 ++spec_l;
                 spec_off += steps;
             }
