@@ -22,114 +22,20 @@
 
 namespace sbtv {
 
-constexpr int SALSA_TAGS = 8 + FSTRIDE;   // completion tags per image: 8 scalars + FSTRIDE prox step sums
-struct Collect {
-    const double *acc;      // rows kernel partials: [batch][3][nrb]           -> resid2
-    int nrb;
-    const double *tvp;      // tvnorm partials [batch][ntv] (initial objective) or null -> post slot 5
-    int ntv;
-    const double *post;     // post kernel partials [batch][6][npb]
-    int npb;
-    // optimistic prox launches (prox_iterate with spec_cur): error partials [batch][FSTRIDE][pnblk] of the psteps iterations
-    // the launches ran without a stop rule; block 7 applies the rule afterwards (null: the prox ran exactly)
-    const double *ppart;
-    int pnblk, psteps, pflip;
-    unsigned long long psum_addr;   // [batch][FSTRIDE] step sums (pinned host memory, as an integer like `out`)
-};
+// images the host has frozen: their prox control block is parked (done = 1)
+__global__ void prox_park_kernel(ProxCtrl *__restrict__ ctrl, const int *__restrict__ frozen, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch && frozen[b]) ctrl[b].done = 1;
+}
 
-// grid (7, batch): block q reduces ONE quantity of SalsaScal (fixed order, deterministic)
-// With rearm = 1 the block that reads the prox control block also re-arms it for the NEXT outer
-// iteration's warm-started prox (k = 0, done = frozen flag, redo = 0, f_valid = 0; lambda / tol /
-// tau / maxiter / cur stay), which saves a separate reset launch per outer iteration.
+// grid (7 [+ psteps], batch): see collect.inc (salsa_collect_block); the same blocks can ride on the first Chambolle
+// launch of the next outer iteration instead (SideJob, tv_fused.inc)
 __global__ __launch_bounds__(256) void salsa_collect_kernel(Collect c, ProxCtrl *__restrict__ ctrl,
                                                              unsigned long long out_addr,
                                                              const int *__restrict__ frozen, int rearm,
                                                              unsigned long long tags_addr, double seq) {
-    // `out` and `tags` may point into pinned host memory.  They travel as integers: a POINTER argument to coherent host
-    // memory makes the runtime end this kernel with a system-scope release (a write-back of every dirty L2 line,
-    // 5-6 us of idle stream before the next kernel); the stores below carry their own system-scope ordering.
-    SalsaScal *__restrict__ out = reinterpret_cast<SalsaScal *>(out_addr);
-    double *__restrict__ tags = reinterpret_cast<double *>(tags_addr);
     __shared__ double red[4];
-    const int b = blockIdx.y, qn = blockIdx.x;
-    if (qn >= 7) {
-        // optimistic prox launches: block 7 + s totals the error partials of Chambolle step s (fixed order) and hands
-        // the sum to the host, which applies the stop rule of chambolle_prox_TV_stop.m:131 over the steps itself
-        const int st = qn - 7;
-        const double *pp = c.ppart + ((size_t)b * FSTRIDE + st) * c.pnblk;
-        double acc = 0.0;
-        constexpr int NB = 8;
-        for (int base = 0; base < c.pnblk; base += 256 * NB) {
-            double v[NB];
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                const int q = base + r * 256 + (int)threadIdx.x;
-                v[r] = (q < c.pnblk) ? __hip_atomic_load(pp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < NB; ++r) acc += v[r];
-        }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double *steps = reinterpret_cast<double *>(c.psum_addr);
-            steps[(size_t)b * FSTRIDE + st] = (red[0] + red[1]) + (red[2] + red[3]);
-            if (tags_addr) {
-                __threadfence_system();
-                __hip_atomic_store(&reinterpret_cast<double *>(tags_addr)[(size_t)b * SALSA_TAGS + 8 + st], seq,
-                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        return;
-    }
-    const double *p = nullptr;
-    int n = 0;
-    if (qn == 0) {
-        p = c.acc ? c.acc + ((size_t)b * 3) * c.nrb : nullptr;
-        n = c.nrb;
-    } else if (qn == 1) {
-        if (c.tvp) {
-            p = c.tvp + (size_t)b * c.ntv;
-            n = c.ntv;
-        } else if (c.post) {
-            p = c.post + ((size_t)b * 6 + 5) * c.npb;
-            n = c.npb;
-        }
-    } else {
-        p = c.post ? c.post + ((size_t)b * 6 + (qn - 2)) * c.npb : nullptr;
-        n = c.npb;
-    }
-    double s = 0.0;
-    if (p)
-        for (int q = threadIdx.x; q < n; q += 256) s += p[q];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double *o = reinterpret_cast<double *>(&out[b]);      // SalsaScal is 8 doubles in this order
-        o[qn] = (red[0] + red[1]) + (red[2] + red[3]);
-        if (qn == 0) {
-            o[7] = ctrl ? (double)ctrl[b].k : 0.0;            // Chambolle iterations booked by exact launches
-            if (ctrl && rearm) {
-                ProxCtrl pc = ctrl[b];
-                pc.k = 0;
-                if (c.ppart && (c.pflip & 1)) pc.cur = (pc.cur & 1) ^ 1;   // optimistic prox with an odd number of launches
-                pc.done = (frozen && frozen[b]) ? 1 : 0;
-                pc.redo = 0;
-                pc.f_valid = 0;
-                pc.err = 0.0;
-                ctrl[b] = pc;
-            }
-        }
-        if (tags) {
-            // completion tag of this scalar (pinned, coherent host memory): the host polls the tags instead of waiting
-            // for an event - an event record costs the stream 5-6 us of idle time per outer iteration
-            __threadfence_system();
-            __hip_atomic_store(&tags[(size_t)b * SALSA_TAGS + qn], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (qn == 0) __hip_atomic_store(&tags[(size_t)b * SALSA_TAGS + 7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    salsa_collect_block(c, ctrl, out_addr, frozen, rearm, tags_addr, seq, blockIdx.x, blockIdx.y, red);
 }
 
 }  // namespace sbtv
@@ -297,7 +203,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         double *o4 = nullptr;
         SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
         if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
-        Collect c{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0, 0ull};
+        Collect c{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0ull};
         hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (ProxCtrl *)nullptr,
                            (unsigned long long)(uintptr_t)scal_d, (const int *)nullptr, 0, 0ull, 0.0);
         SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
@@ -352,9 +258,45 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // `speculate`), so the result is always that of the exact rule.
     // The first outer iteration always runs exactly: from the zero start its prox input is flat and the rule stops at k = 1.
     const bool spec_ok = !(opts->speculate & 2) && !graph_wanted(cnt) && prox_spec_ok(pp, g, u, opts->TViters);
+    static const bool piggyback = [] {
+        const char *e = getenv("SBTV_COLLECT_RIDE");
+        return !(e && e[0] == '0');
+    }();
     bool fired_early = false;
     bool slot_tagged[2] = {false, false}, slot_spec[2] = {false, false};
     long long prox_iters_timed = 0;
+    // The collector of an optimistic iteration does not get a launch of its own when another iteration follows: its
+    // blocks ride on the first Chambolle launch of that next iteration (SideJob; a launch costs ~5 us however little
+    // it does).  `pend` = the collector still to be placed.  Error partials alternate between two sets by iteration
+    // parity, so the riding collector reads one set while its host launch already writes the other.
+    struct PendingCollect {
+        bool valid = false;
+        int outer = 0;
+        bool spec = false;
+    } pend;
+    const int nl_prox = prox_launches(pp, opts->TViters);
+    auto make_collect = [&](int outer, bool spec) -> Collect {
+        const int slot = outer & 1;
+        return Collect{acc, nrb, nullptr, 0, postp, npb, spec ? pp.partials + (size_t)slot * pp.part_stride : nullptr, pp.fnblk,
+                       opts->TViters, (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSTRIDE)};
+    };
+    auto launch_collect = [&](int outer, bool spec, bool tagged) -> int {
+        const int slot = outer & 1;
+        const Collect c = make_collect(outer, spec);
+        // the collector writes the eight scalars straight into pinned host memory (no copy kernel).  Eager launches:
+        // it tags them with the iteration number (the host polls the tags); inside a captured graph the arguments are
+        // frozen, so replay keeps the event
+        hipLaunchKernelGGL(salsa_collect_kernel, dim3(spec ? 7 + opts->TViters : 7, batch), dim3(256), 0, ctx->stream, c, pp.ctrl,
+                           (unsigned long long)(uintptr_t)(scal_hd + (size_t)slot * batch), (const int *)frozen_d, 1,
+                           tagged ? (unsigned long long)(uintptr_t)(tags_hd + (size_t)slot * batch * SALSA_TAGS) : 0ull, (double)outer);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    auto flush_pending = [&]() -> int {
+        if (!pend.valid) return 0;
+        pend.valid = false;
+        return launch_collect(pend.outer, pend.spec, true);
+    };
     auto enqueue_body = [&](int outer, bool eager) -> int {
         const int slot = outer & 1;
         const bool tagged = eager;
@@ -363,14 +305,32 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         // 5-6 us; sbtv_last_timing scales the sampled time to all iterations
         const bool timed = eager && ((outer & 15) == 1);
         slot_tagged[slot] = tagged;
+        slot_spec[slot] = spec;
         double *xn = xbuf[slot];
         const double *xprev = xbuf[slot ^ 1];
-        // (1) TV prox with warm-started duals (:429); the control block was re-armed by the previous
-        //     iteration's collector (or by prox_reset before the loop)
+        // the previous iteration's collector: rides on this iteration's first (optimistic) launch, or gets its own
+        SideJob side{};
+        if (pend.valid && spec) {
+            const int ps = pend.outer & 1;
+            side.c = make_collect(pend.outer, pend.spec);
+            side.out_addr = (unsigned long long)(uintptr_t)(scal_hd + (size_t)ps * batch);
+            side.tags_addr = (unsigned long long)(uintptr_t)(tags_hd + (size_t)ps * batch * SALSA_TAGS);
+            side.frozen = frozen_d;
+            side.seq = (double)pend.outer;
+            side.nblocks = 7 + (pend.spec ? opts->TViters : 0);
+            pend.valid = false;
+        } else {
+            SBTV_TRY(flush_pending());
+        }
+        // (1) TV prox with warm-started duals (:429); the control block was re-armed by the first (exact) iteration's
+        //     collector (or by prox_reset before the loop); optimistic launches leave it alone
         if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p0[slot], ctx->stream));
         // u = g - lambda div p written by the last launch.  Optimistic mode: no stop-rule kernels, no redo pass; the
-        // collector applies the rule over all TViters steps at the end of the iteration
-        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u, false, spec));
+        // host applies the rule over all TViters steps when it reads the iteration's scalars
+        ProxPlan pps = pp;
+        pps.partials = pp.partials + (size_t)slot * pp.part_stride;
+        SBTV_TRY(prox_iterate(ctx, pps, g, opts->TViters, u, false, spec, spec ? ((outer - 2) * nl_prox) & 1 : 0,
+                              side.nblocks ? &side : nullptr));
         if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
         prox_timed[slot] = timed;
         // (2) LS step in the spectral domain + residual energy (:434-444)
@@ -395,18 +355,15 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         cp.xprev = crit2 ? xprev : nullptr;
         cp.partials = postp;
         SBTV_TRY(fft_cols_inv_post(ctx, fp, S, xn, inv_scale, frozen_d, cp));
-        Collect c{acc, nrb, nullptr, 0, postp, npb, spec ? pp.partials : nullptr, pp.fnblk, opts->TViters,
-                  prox_launches(pp, opts->TViters), (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSTRIDE)};
-        // the collector writes the eight scalars straight into pinned host memory (no copy kernel);
-        // they are visible to the host once ev_done has completed
-        // eager launches: the collector tags its scalars with the iteration number (the host polls the tags);
-        // inside a captured graph the arguments are frozen, so replay keeps the event
-        slot_spec[slot] = spec;
-        hipLaunchKernelGGL(salsa_collect_kernel, dim3(spec ? 7 + opts->TViters : 7, batch), dim3(256), 0, ctx->stream, c, pp.ctrl,
-                           (unsigned long long)(uintptr_t)(scal_hd + (size_t)slot * batch), (const int *)frozen_d, 1,
-                           tagged ? (unsigned long long)(uintptr_t)(tags_hd + (size_t)slot * batch * SALSA_TAGS) : 0ull, (double)outer);
-        SBTV_HIP(ctx, hipGetLastError());
-        return 0;
+        // (4) the collector: deferred to the next iteration's first launch when that iteration will exist and be
+        //     optimistic too (the host is then one iteration ahead anyway), else launched here
+        if (spec && eager && lag == 1 && outer < maxiter && piggyback) {
+            pend.valid = true;
+            pend.outer = outer;
+            pend.spec = spec;
+            return 0;
+        }
+        return launch_collect(outer, spec, tagged);
     };
     // Small problems are launch-bound (about a dozen kernels of a few microseconds): from the third outer
     // iteration on, the body of each x-buffer slot is captured once and replayed with one hipGraphLaunch.
@@ -465,6 +422,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // host side of outer iteration `outer`: traces + stopping rule (:444-482)
     auto process = [&](int outer) -> int {
         const int slot = outer & 1;
+        if (pend.valid && pend.outer == outer) SBTV_TRY(flush_pending());     // no later iteration took it along
         if (slot_tagged[slot]) SBTV_TRY(wait_tags(slot, outer));
         else SBTV_TRY(wait_event(ctx, ev_done[slot]));
         if (prox_timed[slot]) {
@@ -522,8 +480,12 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             }
         }
         if (fired_early) return 0;
-        if (changed && active > 0)
+        if (changed && active > 0) {
             SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen_h, sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+            // park the frozen images' prox as well (optimistic launches do not re-arm the control blocks)
+            hipLaunchKernelGGL(prox_park_kernel, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, pp.ctrl, (const int *)frozen_d, batch);
+            SBTV_HIP(ctx, hipGetLastError());
+        }
         return 0;
     };
 

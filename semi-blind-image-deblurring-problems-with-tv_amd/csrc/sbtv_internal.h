@@ -180,7 +180,8 @@ struct ProxPlan {
     int pipe, nbands, nseg, seglen;   // pipe = 1: streaming pipeline kernel (tv_pipe.inc): bands x column segments
     ProxCtrl *ctrl;               // [batch]
     double *pbuf;                 // [2 pingpong][2 (px,py)][batch][M*N]
-    double *partials;             // [batch][nblk]
+    double *partials;             // [2 sets][batch][FSTRIDE][fnblk] (or [batch][nblk] for the one-iteration kernels)
+    size_t part_stride;           // doubles per set
     unsigned *counters;           // [batch] arrival tickets (in-kernel stop-rule path)
 };
 int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan, const char *tag = "prox");
@@ -198,8 +199,36 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);  
 // control block must have been reset with keep_cur = false.
 constexpr int FSMAX = 10;     // most iterations any fused Chambolle kernel runs per LAUNCH
 constexpr int FSTRIDE = 32;   // step slots of the error partials [batch][FSTRIDE][nblk]: most iterations of an optimistic prox
+// ---- SALSA collector: what it reduces (salsa.hip launches it; the Chambolle kernels can host its blocks, tv_fused.inc)
+constexpr int SALSA_TAGS = 8 + FSTRIDE;   // completion tags per image: 8 scalars + FSTRIDE prox step sums
+struct Collect {
+    const double *acc;      // rows kernel partials: [batch][3][nrb]           -> resid2
+    int nrb;
+    const double *tvp;      // tvnorm partials [batch][ntv] (initial objective) or null -> post slot 5
+    int ntv;
+    const double *post;     // post kernel partials [batch][6][npb]
+    int npb;
+    // optimistic prox launches: error partials [batch][FSTRIDE][pnblk] of the psteps iterations the launches ran
+    // without a stop rule (null: the prox ran exactly); blocks 7.. total one step each for the host's rule
+    const double *ppart;
+    int pnblk, psteps;
+    unsigned long long psum_addr;   // [batch][FSTRIDE] step sums (pinned host memory, as an integer like `out`)
+};
+// A collector that rides on another kernel's launch: the first `nblocks` workgroups of that grid run its blocks
+// (a launch costs ~5 us however little it does; these blocks finish long before the host kernel's own work)
+struct SideJob {
+    Collect c;
+    unsigned long long out_addr, tags_addr;
+    const int *frozen;
+    double seq;
+    int nblocks;            // 0: no side job
+};
+#ifdef __HIPCC__
+#include "collect.inc"
+#endif
+
 int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr,
-                 bool cold = false, bool spec = false);
+                 bool cold = false, bool spec = false, int spec_parity = 0, const SideJob *side = nullptr);
 int prox_launches(const ProxPlan &pl, int maxiter);
 bool prox_spec_ok(const ProxPlan &pl, const double *g, const double *f_out, int maxiter);
 // f = g - lambda * div(p)

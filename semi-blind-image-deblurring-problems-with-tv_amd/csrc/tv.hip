@@ -647,7 +647,10 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     const std::string t(tag ? tag : "prox");          // a second concurrent prox (CoRAL) needs its own state
     SBTV_TRY(ws_get_t(ctx, (t + ".ctrl").c_str(), (size_t)batch, &pl->ctrl));
     SBTV_TRY(ws_get_t(ctx, (t + ".pbuf").c_str(), 4 * P * batch, &pl->pbuf));
-    SBTV_TRY(ws_get_t(ctx, (t + ".partials").c_str(), npart, &pl->partials));
+    // two sets: a solver loop whose collector rides on the next iteration's first launch reads one while that
+    // launch already writes the other (salsa.hip)
+    SBTV_TRY(ws_get_t(ctx, (t + ".partials").c_str(), 2 * npart, &pl->partials));
+    pl->part_stride = npart;
     // arrival tickets of the in-kernel control path: zero between launches (the last workgroup resets it)
     SBTV_TRY(ws_get_t(ctx, (t + ".counters").c_str(), (size_t)batch, &pl->counters));
     SBTV_HIP(ctx, hipMemsetAsync(pl->counters, 0, sizeof(unsigned) * batch, ctx->stream));
@@ -710,8 +713,10 @@ int prox_launches(const ProxPlan &pl, int maxiter) {
 // spec: optimistic mode for solver loops (see the kernels, bit 2 of their flag word): the launches run all `maxiter`
 // iterations back to back, launch l from dual buffer cur ^ (l & 1), WITHOUT stop-rule kernels and without the redo
 // pass; the error partials of step s land in slot s and the control blocks are left untouched.  The caller evaluates
-// the rule over the maxiter steps, flips `cur` when prox_launches() is odd, and re-runs exactly if the rule fired early.
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold, bool spec) {
+// the rule over the maxiter steps and re-runs exactly if it fired early; spec_parity = parity of the optimistic launches
+// made since `cur` was last written (the kernels read cur ^ parity); `side`: a collector to host in the first launch.
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold, bool spec,
+                 int spec_parity, const SideJob *side) {
     const bool spec_cur = spec;
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
     const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
@@ -720,7 +725,8 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: optimistic mode is not available for this plan");
     if (v && !env_single && !g_force_single_step && (!f_out || vec_ok(f_out, pl.M))) {
         // temporally fused path: ceil(K/FH) launches of (nearly) equal step counts + the redo pair
-        const dim3 fgrid(pl.fnblk, 1, pl.batch);   // linear tile list, remapped per XCD inside the kernel
+        dim3 fgrid(pl.fnblk, 1, pl.batch);         // linear tile list, remapped per XCD inside the kernel
+        const SideJob no_side{};
         const int per_launch = pl.pipe ? PK : FHJ;
         const int nl = (maxiter + per_launch - 1) / per_launch;
         const int base = maxiter / nl, extra = maxiter % nl;
@@ -734,10 +740,13 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         int spec_off = 0, spec_l = 0;                           // steps / launches already made (optimistic mode)
         auto launch_fused = [&](int steps, int redo, int write_f) -> int {
             bool launched = false;
+            // the first optimistic launch can host the collector of the previous outer iteration
+            const SideJob &sj = (spec_cur && side && spec_l == 0) ? *side : no_side;
+            fgrid.x = pl.fnblk + sj.nblocks;
             const int inl = (!redo && env_inline && !spec_cur) ? 1 : 0;
             int kflags = inl | (cold ? 2 : 0);                  // bit 0: in-kernel stop rule, bit 1: cold start
             if (spec_cur) {                                      // bit 2 + source / destination buffer + first step slot
-                kflags = 4 | (cold ? 2 : 0) | ((spec_l & 1) << 8) | (spec_off << 12);
+                kflags = 4 | (cold ? 2 : 0) | ((spec_l & 1) << 8) | ((spec_parity & 1) << 9) | (spec_off << 12);
                 ++spec_l;
                 spec_off += steps;
             }
@@ -758,11 +767,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
                                g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
-                               redo, f_out, write_f, pl.counters, kflags);                                   \
+                               redo, f_out, write_f, pl.counters, kflags, sj);                               \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags);                  \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);              \
     }
             SBTV_FUSED_CASE(8, 4, 2)
             SBTV_FUSED_CASE(8, 8, 2)
@@ -786,11 +795,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused1_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags);                             \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);                         \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused1_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,            \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags);                             \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);                         \
     }
             SBTV_FUSED1_CASE(4, 8, 6)
             SBTV_FUSED1_CASE(4, 8, 5)
