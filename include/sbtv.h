@@ -47,6 +47,10 @@ extern "C" {
 /* sbtv_SAPG_algorithm only: */
 #define SBTV_REDUCE_DEVICE  2   /* reduce_fn is an sbtv_allreduce_dev_fn (in-stream collective on a device buffer)  */
 #define SBTV_SAPG_HOST_LOOP 4   /* parameter updates on the host, one synchronisation per iteration (the round-1 loop) */
+/* sbtv_fista_tv only: */
+#define SBTV_FISTA_EXACT_PROX 2 /* stop-rule kernel after every Chambolle launch (default: the launches of a prox run all
+                                 * prox_iters iterations, the host applies the rule of chambolle_prox_TV_stop.m:131 over the
+                                 * steps afterwards and repeats the call with this flag if it stopped early) */
 
 /* status codes */
 #define SBTV_OK                   0

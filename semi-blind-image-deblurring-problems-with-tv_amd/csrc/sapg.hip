@@ -50,9 +50,33 @@ __global__ __launch_bounds__(256) void sapg_collect_kernel(const double *__restr
 __global__ __launch_bounds__(256) void fista_collect_kernel(const double *__restrict__ acc, int nrb,
                                                             const double *__restrict__ mom, int npb,
                                                             const double *__restrict__ tvp, int ntv,
-                                                            double *__restrict__ out, int batch) {
+                                                            double *__restrict__ out, int batch,
+                                                            const double *__restrict__ ppart, int pnblk) {
     __shared__ double red[4];
     const int q = blockIdx.x, b = blockIdx.y;
+    if (q >= 7) {
+        // optimistic prox launches (prox_iterate, spec): block 7 + s totals the error partials of Chambolle step s into
+        // out[8*batch + b*FSTRIDE + s]; the host applies the stop rule of chambolle_prox_TV_stop.m:131 over the steps
+        const int st = q - 7;
+        const double *pp = ppart + ((size_t)b * FSTRIDE + st) * pnblk;
+        double a = 0.0;
+        constexpr int NB = 8;
+        for (int base = 0; base < pnblk; base += 256 * NB) {
+            double v[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int i = base + r * 256 + (int)threadIdx.x;
+                v[r] = (i < pnblk) ? __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) a += v[r];
+        }
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) out[8 * (size_t)batch + (size_t)b * FSTRIDE + st] = (red[0] + red[1]) + (red[2] + red[3]);
+        return;
+    }
     const double *p;
     int n;
     size_t o;
@@ -366,7 +390,7 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     double *scal_h = nullptr, *scal_hd = nullptr;      // pinned [acc3 | mom3 | tv | pad] per image, host / device view
     {
         void *pz = nullptr, *dp = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(double) * 8 * batch, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * (8 + FSTRIDE) * batch, &pz));     // + the prox step sums of an optimistic prox
         scal_h = static_cast<double *>(pz);
         SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
         scal_hd = static_cast<double *>(dp);
@@ -399,6 +423,11 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     // objective(k) = 0.5*||A x - b||^2 + tau*Phi(x) ; mses(k)   (:14-15, :31-33)
     // residual energy (Parseval) and TV partials of x, then ONE collector launch that reduces them (and the
     // momentum-kernel sums when given) straight into pinned host memory
+    // Optimistic prox launches (no stop-rule kernels, no redo pass: 6 launches less per iteration); the host applies the
+    // rule over the prox_iters step sums when it reads the iteration's scalars and, should it have stopped early, repeats
+    // the whole call with exact launches (flag SBTV_FISTA_EXACT_PROX), so the result is always that of the exact rule.
+    const bool prox_spec = !(flags & SBTV_FISTA_EXACT_PROX) && prox_spec_ok(pp, y, x, prox_iters);
+    bool prox_was_spec = false;
     auto objective_of_x = [&](const int *frozen, const double *mom_partials) -> int {
         RowsArgs a{};
         a.dir_fwd = 1;
@@ -412,8 +441,9 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         double *tvp = nullptr;
         int ntv = 0;
         SBTV_TRY(tvnorm_partials(ctx, x, M, N, batch, &tvp, &ntv));
-        hipLaunchKernelGGL(fista_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
-                           mom_partials, npb, (const double *)tvp, ntv, scal_hd, batch);
+        hipLaunchKernelGGL(fista_collect_kernel, dim3(prox_was_spec ? 7 + prox_iters : 7, batch), dim3(256), 0, ctx->stream,
+                           (const double *)acc, nrb, mom_partials, npb, (const double *)tvp, ntv, scal_hd, batch,
+                           (const double *)pp.partials, pp.fnblk);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
@@ -463,11 +493,24 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             }
         }
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
-        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x, true));
+        prox_was_spec = prox_spec;
+        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x, true, prox_spec));
         t = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                     // :28
         SBTV_TRY(fista_momentum(ctx, x, xold, y, td, (t_old - 1) / t, momp, P, batch, frozen_d));   // :29
         SBTV_TRY(objective_of_x(frozen_d, momp));
         SBTV_TRY(fetch());
+        if (prox_spec) {
+            // cont = (k < MaxIter) & (err > tol)  (chambolle_prox_TV_stop.m:131; tol 1e-3 as armed above)
+            bool fired = false;
+            for (int b = 0; b < batch && !fired; ++b) {
+                if (frozen[b]) continue;
+                const double *ps = scal_h + 8 * (size_t)batch + (size_t)b * FSTRIDE;
+                for (int kk = 1; kk < prox_iters && !fired; ++kk) fired = !(sqrt(ps[kk - 1]) > 1e-3);
+            }
+            if (fired)
+                return sbtv_fista_tv(ctx, bimg, M, N, batch, taps, taille, tau, L, prox_iters, stopcriterion, tolerance, maxiters,
+                                     zero_start, true_x, x_out, objective, mses, n_iter, flags | SBTV_FISTA_EXACT_PROX);
+        }
         bool changed = false;
         for (int b = 0; b < batch; ++b) {
             if (frozen[b]) continue;
