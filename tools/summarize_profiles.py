@@ -68,7 +68,10 @@ def main():
         loop = ("chambolle_fused_kernel", "chambolle_pipe_kernel", "chambolle_fused_ctrl_kernel", "fft_cols_fwd_kernel",
                 "cols_fwd_wave_kernel", "fft_rows_kernel", "rows_wave_kernel", "rows_pipe_kernel", "fft_cols_inv_kernel",
                 "cols_inv_wave_kernel", "salsa_collect_kernel")
-        n_outer = max(len(per.get(k, [])) for k in per if k.startswith("salsa_collect_kernel"))
+        # outer iterations = launches of the inverse column pass with the SALSA bookkeeping (the collector has no launch of
+        # its own any more: it rides on the next iteration's first Chambolle launch)
+        post = [len(v) for k, v in per.items() if k.startswith(("cols_inv_wave_kernel", "fft_cols_inv_kernel"))]
+        n_outer = max(post) if post else max(len(per.get(k, [])) for k in per if k.startswith("salsa_collect_kernel"))
         kernels, total = {}, 0.0
         for k, c in res.items():
             if not k.startswith(loop) or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
