@@ -344,6 +344,28 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double
     double2 v[8], m[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = in[t + s * T];
+    // Small images (M <= 512: at most 256 workgroups of 64 threads, one per CU): the pass is a chain of memory round
+    // trips, so the bookkeeping streams of the epilogue are requested here, together with the spectrum column, instead
+    // of element by element after the transform (the compiler waits for every element's loads separately there).
+    constexpr bool PREP = POST && (LOG2N <= 8);
+    double2 pu[PREP ? 8 : 1], pb[PREP ? 8 : 1], pt[PREP ? 8 : 1], pul[PREP ? 8 : 1], pxo[PREP ? 8 : 1];
+    double pup[PREP ? 8 : 1];
+    if constexpr (PREP) {
+        constexpr int M = 2 * n;
+        const size_t ibase = (size_t)b * N * M, cb = ibase + (size_t)j * M;
+        const size_t cl = ibase + (size_t)(j > 0 ? j - 1 : N - 1) * M;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int e = t + s * T;
+            const size_t o = cb + 2 * (size_t)e;
+            pu[s] = *reinterpret_cast<const double2 *>(post.u + o);
+            pb[s] = *reinterpret_cast<const double2 *>(post.bu + o);
+            if (post.tru) pt[s] = nt_load2(post.tru + o);
+            if (post.xprev) pxo[s] = *reinterpret_cast<const double2 *>(post.xprev + o);
+            pup[s] = post.u[e > 0 ? o - 1 : cb + M - 1];
+            pul[s] = *reinterpret_cast<const double2 *>(post.u + cl + 2 * (size_t)e);
+        }
+    }
     mirror<LOG2N>(v, m, t, X);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -375,14 +397,14 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double
             const size_t o = cb + 2 * (size_t)e;
             const double2 xv = cscale(v[s], scale);
             nt_store2(reinterpret_cast<double *>(out + e), xv);       // x is not read again in this iteration
-            const double2 uv = *reinterpret_cast<const double2 *>(post.u + o);
-            double2 bv = *reinterpret_cast<const double2 *>(post.bu + o);
+            const double2 uv = PREP ? pu[PREP ? s : 0] : *reinterpret_cast<const double2 *>(post.u + o);
+            double2 bv = PREP ? pb[PREP ? s : 0] : *reinterpret_cast<const double2 *>(post.bu + o);
             bv.x = bv.x + (uv.x - xv.x);
             bv.y = bv.y + (uv.y - xv.y);
             *reinterpret_cast<double2 *>(post.bu + o) = bv;
             *reinterpret_cast<double2 *>(post.g + o) = make_double2(xv.x - bv.x, xv.y - bv.y);
             if (post.tru) {
-                const double2 tv = nt_load2(post.tru + o);
+                const double2 tv = PREP ? pt[PREP ? s : 0] : nt_load2(post.tru + o);
                 const double e0 = xv.x - tv.x, e1 = xv.y - tv.y;
                 acc[0] += e0 * e0 + e1 * e1;
             }
@@ -391,13 +413,13 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_inv_kernel(const double
             acc[2] += xv.x * xv.x + xv.y * xv.y;
             acc[3] += uv.x * uv.x + uv.y * uv.y;
             if (post.xprev) {
-                const double2 xo = *reinterpret_cast<const double2 *>(post.xprev + o);
+                const double2 xo = PREP ? pxo[PREP ? s : 0] : *reinterpret_cast<const double2 *>(post.xprev + o);
                 const double p0 = xv.x - xo.x, p1 = xv.y - xo.y;
                 acc[4] += p0 * p0 + p1 * p1;
             }
             // periodic isotropic TV of u (utils/TVnorm.m:2)
-            const double up = post.u[e > 0 ? o - 1 : cb + M - 1];
-            const double2 ul = *reinterpret_cast<const double2 *>(post.u + cl + 2 * (size_t)e);
+            const double up = PREP ? pup[PREP ? s : 0] : post.u[e > 0 ? o - 1 : cb + M - 1];
+            const double2 ul = PREP ? pul[PREP ? s : 0] : *reinterpret_cast<const double2 *>(post.u + cl + 2 * (size_t)e);
             const double h0 = uv.x - ul.x, v0 = uv.x - up, h1 = uv.y - ul.y, v1 = uv.y - uv.x;
             acc[5] += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
         }
@@ -508,14 +530,46 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
     auto uidx = [&](int kk, int l) -> size_t { return (TILED && p.u_tiled) ? u_tiled(kk, l, n1) : (size_t)l * (n1 + 1) + kk; };
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = in[sidx(t + s * T)];
+    // Small workgroups (<= 256 threads: images up to 512^2 and the RK = 1 / 2 variants) have registers to spare and are
+    // bound by the chain of memory round trips, not by throughput: they request the operator spectra of their row
+    // together with the row itself, BEFORE the forward transform (one round trip instead of nine: written as a loop
+    // the compiler waits for every spectrum value separately).  The workgroup with the packed row 0 keeps the loop.
+    constexpr bool PRE = (OP != OP_NONE) && (RK * T <= 256);
+    constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF);
+    constexpr bool needD = (OP == OP_GRAD);
+    const size_t hbase = p.shared_spec ? 0 : (size_t)b * p.u_img;
+    double2 hh[PRE ? 8 : 1], yy[(PRE && needY) ? 8 : 1], dd1[(PRE && needD) ? 8 : 1], dd2[(PRE && needD) ? 8 : 1];
+    // spectrum row M/2, for the thread row that owns the packed row 0 (its own row k = 0 is covered by hh / yy)
+    double2 hq[PRE ? 8 : 1], yq[(PRE && needY) ? 8 : 1], d1q[(PRE && needD) ? 8 : 1], d2q[(PRE && needD) ? 8 : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const size_t hi = hbase + uidx(k, t + s * T);
+            hh[s] = p.H[hi];
+            if constexpr (needY) yy[s] = p.Y[hi];
+            if constexpr (needD) {
+                dd1[s] = p.D1[hi];
+                dd2[s] = p.D2[hi];
+            }
+        }
+        if (kb == 0 && q == 0) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const size_t hn = hbase + uidx(n1, t + s * T);
+                hq[s] = p.H[hn];
+                if constexpr (needY) yq[s] = p.Y[hn];
+                if constexpr (needD) {
+                    d1q[s] = p.D1[hn];
+                    d2q[s] = p.D2[hn];
+                }
+            }
+        }
+    }
     if (p.fwd) fft_stages<LOG2N, 0, false>(v, t, p.tw, X);
 
     double acc[3] = {0.0, 0.0, 0.0};
     if constexpr (OP != OP_NONE) {
-        const size_t hbase = p.shared_spec ? 0 : (size_t)b * p.u_img;
         const double mu = p.mu ? p.mu[b] : 0.0;
-        constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF);
-        constexpr bool needD = (OP == OP_GRAD);
         if (kb == 0) {
             // the block that owns the packed row 0 = X[0,:] + i X[M/2,:]
             double2 m[8];
@@ -525,24 +579,39 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsPa
                 const int l = t + s * T;
                 const size_t hi = hbase + uidx(0, l);
                 const size_t hin = hbase + uidx(n1, l), hik = hbase + uidx(k, l);
+                const double2 z = make_double2(0.0, 0.0);
                 if (q == 0) {
                     const double2 P = v[s], Q = cconj(m[s]);
                     const double2 A = cscale(cadd(P, Q), 0.5);
                     const double2 dB = csub(P, Q);
                     const double2 B = make_double2(0.5 * dB.y, -0.5 * dB.x);   // (P-Q)/(2i)
-                    const double2 z = make_double2(0.0, 0.0);
-                    const double2 A2 = spec_apply<OP>(A, p.H[hi], needY ? p.Y[hi] : z, needD ? p.D1[hi] : z,
-                                                      needD ? p.D2[hi] : z, mu, 1.0, acc);
-                    const double2 B2 = spec_apply<OP>(B, p.H[hin], needY ? p.Y[hin] : z,
-                                                      needD ? p.D1[hin] : z, needD ? p.D2[hin] : z, mu, 1.0,
-                                                      acc);
+                    double2 A2, B2;
+                    if constexpr (PRE) {
+                        A2 = spec_apply<OP>(A, hh[s], needY ? yy[needY ? s : 0] : z, needD ? dd1[needD ? s : 0] : z,
+                                            needD ? dd2[needD ? s : 0] : z, mu, 1.0, acc);
+                        B2 = spec_apply<OP>(B, hq[s], needY ? yq[needY ? s : 0] : z, needD ? d1q[needD ? s : 0] : z,
+                                            needD ? d2q[needD ? s : 0] : z, mu, 1.0, acc);
+                    } else {
+                        A2 = spec_apply<OP>(A, p.H[hi], needY ? p.Y[hi] : z, needD ? p.D1[hi] : z, needD ? p.D2[hi] : z, mu,
+                                            1.0, acc);
+                        B2 = spec_apply<OP>(B, p.H[hin], needY ? p.Y[hin] : z, needD ? p.D1[hin] : z,
+                                            needD ? p.D2[hin] : z, mu, 1.0, acc);
+                    }
                     v[s] = make_double2(A2.x - B2.y, A2.y + B2.x);             // A' + i B'
+                } else if constexpr (PRE) {
+                    v[s] = spec_apply<OP>(v[s], hh[s], needY ? yy[needY ? s : 0] : z, needD ? dd1[needD ? s : 0] : z,
+                                          needD ? dd2[needD ? s : 0] : z, mu, 2.0, acc);
                 } else {
-                    const double2 z = make_double2(0.0, 0.0);
                     v[s] = spec_apply<OP>(v[s], p.H[hik], needY ? p.Y[hik] : z, needD ? p.D1[hik] : z,
                                           needD ? p.D2[hik] : z, mu, 2.0, acc);
                 }
             }
+        } else if constexpr (PRE) {
+            const double2 z = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                v[s] = spec_apply<OP>(v[s], hh[s], needY ? yy[needY ? s : 0] : z, needD ? dd1[needD ? s : 0] : z,
+                                      needD ? dd2[needD ? s : 0] : z, mu, 2.0, acc);
         } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {

@@ -1,10 +1,16 @@
 #!/bin/bash
-# per-launch kernel durations of a few SALSA iterations in launch order (run on the GPU box): bash tools/trace_seq.sh
+# per-launch kernel durations and the gaps between consecutive launches of the last SALSA outer iterations (run on the
+# GPU box): bash tools/trace_seq.sh [size]        size = 2048 (default, bench.py) or a small size (tools/trace_small.py)
 set -eo pipefail
 export TMPDIR=/tmp
 R=$PWD
+SIZE=${1:-2048}
 O=$R/gpurun_out/trace_seq; rm -rf "$O"
-(cd /tmp; rocprofv3 --kernel-trace --output-format csv -d "$O" -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-batched --no-extras > "$O.log" 2>&1)
+if [ "$SIZE" = "2048" ]; then
+  (cd /tmp; rocprofv3 --kernel-trace --output-format csv -d "$O" -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-batched --no-extras > "$O.log" 2>&1)
+else
+  (cd /tmp; rocprofv3 --kernel-trace --output-format csv -d "$O" -- python3 $R/tools/trace_small.py $SIZE 40 > "$O.log" 2>&1)
+fi
 python3 - "$O" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
@@ -15,7 +21,6 @@ out = []
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     out.append((r["Kernel_Name"][:42], (s - t0) / 1e3, (e - s) / 1e3))
-# last ~40 launches
 prev_end = None
 for name, s, d in out[-45:]:
     gap = (s - prev_end) if prev_end is not None else 0.0
