@@ -834,9 +834,16 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         return myula_step(ctx, X, prox, grad, nullptr, sig_d, gam, lamb, P, batch, &r, &arm);
     };
     // prox = chambolle(X, lambda*theta, cold start); armed: the MYULA step before it has reset the control blocks
+    // Inside the device-resident loop the prox runs in the multi-buffer optimistic mode: its Chambolle launches go back to
+    // back without stop-rule work in between (in-kernel or as separate kernels that costs 4-5 us per launch), every
+    // launch boundary keeps its duals, one small kernel applies the rule over all steps and a (normally empty) redo
+    // launch re-runs the steps up to an early stop.  Early stops DO happen here (small lambda*theta: err falls below
+    // 1e-3 within the 25 iterations), so unlike SALSA / FISTA this path must handle them in place.
+    const bool prox_mb = dev_loop && prox_spec_ok(pp, X, prox, op->chambolleit);
+    if (prox_mb) SBTV_TRY(prox_reserve_pairs(ctx, &pp, prox_launches(pp, op->chambolleit) + 2));
     auto do_prox = [&](bool armed) -> int {
         if (!armed) SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
-        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox, true));
+        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox, true, (armed && prox_mb) ? 2 : 0));
         return 0;
     };
 

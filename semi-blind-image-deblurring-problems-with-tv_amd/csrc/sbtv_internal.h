@@ -179,7 +179,9 @@ struct ProxPlan {
     int cj, nw, minw, rpl;        // fused-kernel variant of this plan (columns per wave, waves, waves/SIMD, rows per lane)
     int pipe, nbands, nseg, seglen;   // pipe = 1: streaming pipeline kernel (tv_pipe.inc): bands x column segments
     ProxCtrl *ctrl;               // [batch]
-    double *pbuf;                 // [2 pingpong][2 (px,py)][batch][M*N]
+    double *pbuf;                 // [pairs][2 (px,py)][batch][M*N]; pairs = 2 (ping-pong) unless prox_reserve_pairs() asked for more
+    int pairs;
+    std::string tag;              // workspace name prefix
     double *partials;             // [2 sets][batch][FSTRIDE][fnblk] (or [batch][nblk] for the one-iteration kernels)
     size_t part_stride;           // doubles per set
     unsigned *counters;           // [batch] arrival tickets (in-kernel stop-rule path)
@@ -228,7 +230,8 @@ struct SideJob {
 #endif
 
 int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out = nullptr,
-                 bool cold = false, bool spec = false, int spec_parity = 0, const SideJob *side = nullptr);
+                 bool cold = false, int spec = 0, int spec_parity = 0, const SideJob *side = nullptr);
+int prox_reserve_pairs(sbtv_ctx *ctx, ProxPlan *pl, int pairs);
 int prox_launches(const ProxPlan &pl, int maxiter);
 bool prox_spec_ok(const ProxPlan &pl, const double *g, const double *f_out, int maxiter);
 // f = g - lambda * div(p)

@@ -422,6 +422,67 @@ __global__ __launch_bounds__(64 * FSMAX) void chambolle_fused_ctrl_kernel(ProxCt
     }
 }
 
+// Stop rule of a multi-buffer optimistic prox (prox_iterate, mode 2): the launches ran all `total` iterations of a COLD
+// prox, launch l of `base` (+1 for the first `extra`) steps from dual buffer l into buffer l + 1.  One workgroup per
+// image totals the error partials of every step (fixed order) and applies cont = (k < MaxIter) & (err > tol)
+// (chambolle_prox_TV_stop.m:131).  Stopped at the last step: the f the last launch wrote stands (f_valid).  Stopped at
+// an earlier k: `cur` = the buffer of the launch boundary before k, `redo` = the steps from there to k; the redo
+// launch that follows re-runs them and rewrites f.
+__global__ __launch_bounds__(64 * FSMAX) void chambolle_mb_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
+                                                                    const double *__restrict__ partials, int nblk, int total,
+                                                                    int base, int extra) {
+    const int b = blockIdx.x;
+    __shared__ double tots[FSTRIDE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int st = w; st < total; st += FSMAX) {
+        const double *p = partials + ((size_t)b * FSTRIDE + st) * nblk;
+        double acc = 0.0;
+        constexpr int NB = 16;
+        for (int q0 = 0; q0 < nblk; q0 += 64 * NB) {
+            double v[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int q = q0 + r * 64 + lane;
+                v[r] = (q < nblk) ? __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) acc += v[r];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tots[st] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    ProxCtrl c = ctrl[b];
+    if (c.done) return;                         // parked image
+    int k = total;
+    for (int st = 0; st < total; ++st) {
+        if (!((st + 1 < total) && (sqrt(tots[st]) > c.tol))) {
+            k = st + 1;
+            break;
+        }
+    }
+    c.k = k;
+    c.err = sqrt(tots[k - 1]);
+    c.done = 1;
+    if (k == total) {
+        c.redo = 0;
+        c.f_valid = 1;
+    } else {
+        // launch l covers steps [start_l, start_l + len_l): find the one holding step k
+        int l = 0, start = 0;
+        for (;; ++l) {
+            const int len = base + (l < extra ? 1 : 0);
+            if (k <= start + len) break;
+            start += len;
+        }
+        c.cur = l;                              // dual buffer at the launch boundary before k (0 = the cold start)
+        c.redo = k - start;
+        c.f_valid = 0;
+    }
+    ctrl[b] = c;
+}
+
 // Sum the per-block partials in a fixed order, then apply the stop rule
 // cont = (k < MaxIter) & (err > tol)   (chambolle_prox_TV_stop.m:131)
 __global__ __launch_bounds__(256) void chambolle_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
@@ -647,6 +708,8 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     const std::string t(tag ? tag : "prox");          // a second concurrent prox (CoRAL) needs its own state
     SBTV_TRY(ws_get_t(ctx, (t + ".ctrl").c_str(), (size_t)batch, &pl->ctrl));
     SBTV_TRY(ws_get_t(ctx, (t + ".pbuf").c_str(), 4 * P * batch, &pl->pbuf));
+    pl->pairs = 2;
+    pl->tag = t;
     // two sets: a solver loop whose collector rides on the next iteration's first launch reads one while that
     // launch already writes the other (salsa.hip)
     SBTV_TRY(ws_get_t(ctx, (t + ".partials").c_str(), 2 * npart, &pl->partials));
@@ -654,6 +717,16 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     // arrival tickets of the in-kernel control path: zero between launches (the last workgroup resets it)
     SBTV_TRY(ws_get_t(ctx, (t + ".counters").c_str(), (size_t)batch, &pl->counters));
     SBTV_HIP(ctx, hipMemsetAsync(pl->counters, 0, sizeof(unsigned) * batch, ctx->stream));
+    return 0;
+}
+
+// more dual buffers (pairs of px, py planes) for the multi-buffer optimistic mode: launches + 2
+int prox_reserve_pairs(sbtv_ctx *ctx, ProxPlan *pl, int pairs) {
+    if (pairs <= pl->pairs) return 0;
+    if (pairs > 15) return fail(ctx, SBTV_ERR_BADARG, "prox_reserve_pairs: at most 15 dual buffers");
+    const size_t P = (size_t)pl->M * pl->N;
+    SBTV_TRY(ws_get_t(ctx, (pl->tag + ".pbuf").c_str(), (size_t)2 * pairs * P * pl->batch, &pl->pbuf));
+    pl->pairs = pairs;
     return 0;
 }
 
@@ -715,9 +788,14 @@ int prox_launches(const ProxPlan &pl, int maxiter) {
 // pass; the error partials of step s land in slot s and the control blocks are left untouched.  The caller evaluates
 // the rule over the maxiter steps and re-runs exactly if it fired early; spec_parity = parity of the optimistic launches
 // made since `cur` was last written (the kernels read cur ^ parity); `side`: a collector to host in the first launch.
-int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold, bool spec,
+int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter, double *f_out, bool cold, int spec,
                  int spec_parity, const SideJob *side) {
-    const bool spec_cur = spec;
+    // spec: 0 exact launches, 1 optimistic ping-pong launches (warm or cold; the caller checks the rule), 2 multi-buffer
+    // optimistic launches of a cold prox with the rule applied and honoured right after them (see the kernels, bit 3)
+    const bool spec_cur = spec != 0;
+    const bool mb = spec == 2;
+    if (mb && (!cold || !f_out || (size_t)pl.pairs < (size_t)prox_launches(pl, maxiter) + 2))
+        return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: the multi-buffer mode needs a cold prox with f output and prox_reserve_pairs()");
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
     const bool v = vec_ok(g, pl.M) && vec_ok(pl.pbuf, pl.M);
     static const bool env_single = (getenv("SBTV_SINGLE_STEP") != nullptr);
@@ -746,9 +824,17 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             const int inl = (!redo && env_inline && !spec_cur) ? 1 : 0;
             int kflags = inl | (cold ? 2 : 0);                  // bit 0: in-kernel stop rule, bit 1: cold start
             if (spec_cur) {                                      // bit 2 + source / destination buffer + first step slot
-                kflags = 4 | (cold ? 2 : 0) | ((spec_l & 1) << 8) | ((spec_parity & 1) << 9) | (spec_off << 12);
-                ++spec_l;
-                spec_off += steps;
+                if (mb && redo) {
+                    kflags = 4 | 8 | 2 | ((nl + 1) << 24);       // from the buffer the stop-rule kernel names into the spare one
+                } else if (mb) {
+                    kflags = 4 | 8 | 2 | (spec_off << 12) | (spec_l << 20) | ((spec_l + 1) << 24);
+                } else {
+                    kflags = 4 | (cold ? 2 : 0) | ((spec_l & 1) << 8) | ((spec_parity & 1) << 9) | (spec_off << 12);
+                }
+                if (!redo) {
+                    ++spec_l;
+                    spec_off += steps;
+                }
             }
             if (pl.pipe) {
                 launched = true;
@@ -821,6 +907,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         };
         const int wf = f_out ? 1 : 0;
         for (int l = 0; l < nl; ++l) SBTV_TRY(launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0));
+        if (mb) {
+            hipLaunchKernelGGL(chambolle_mb_ctrl_kernel, dim3(pl.batch), dim3(64 * FSMAX), 0, ctx->stream, pl.ctrl, pl.partials,
+                               pl.fnblk, maxiter, base, extra);
+            SBTV_TRY(launch_fused(0, 1, wf));                    // re-runs the steps up to an early stop (normally empty)
+        }
         if (!spec_cur) SBTV_TRY(launch_fused(0, 1, wf));     // redo pass; doubles as the finish-only pass when f is not valid yet
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
