@@ -104,16 +104,6 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const size_t npar = (size_t)batch * taille * taille + 2 * (size_t)batch;
     SBTV_TRY(ws_get_t(ctx, "salsa.par", npar, &par));
     double *taps_d = par, *mu_d = par + (size_t)batch * taille * taille, *thr_d = mu_d + batch;
-    {
-        std::vector<double> h(npar);
-        for (size_t q = 0; q < (size_t)batch * taille * taille; ++q) h[q] = taps[q];
-        for (int b = 0; b < batch; ++b) {
-            h[(size_t)batch * taille * taille + b] = mu[b];
-            h[(size_t)batch * taille * taille + batch + b] = tau[b] / mu[b];   // threshold = tau/mu (:394)
-        }
-        SBTV_HIP(ctx, hipMemcpyAsync(par, h.data(), sizeof(double) * npar, hipMemcpyHostToDevice, ctx->stream));
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h goes out of scope
-    }
     int *frozen_d = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.frozen", (size_t)batch, &frozen_d));
     SBTV_HIP(ctx, hipMemsetAsync(frozen_d, 0, sizeof(int) * batch, ctx->stream));
@@ -129,22 +119,36 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     int *frozen_h = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 2 * batch + sizeof(double) * 2 * batch * (FSTRIDE + SALSA_TAGS) + sizeof(int) * batch, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(SalsaScal) * 3 * batch + sizeof(double) * batch * (2 * FSTRIDE + 3 * SALSA_TAGS) + sizeof(int) * batch +
+                                     sizeof(double) * npar, &pz));
         scal_h = static_cast<SalsaScal *>(pz);
         void *dp = nullptr;
         SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
         scal_hd = static_cast<SalsaScal *>(dp);
-        frozen_h = reinterpret_cast<int *>(reinterpret_cast<double *>(scal_h + 2 * (size_t)batch) + 2 * (size_t)batch * (FSTRIDE + SALSA_TAGS));
+        frozen_h = reinterpret_cast<int *>(reinterpret_cast<double *>(scal_h + 3 * (size_t)batch) + (size_t)batch * (2 * FSTRIDE + 3 * SALSA_TAGS) + npar);
         for (int b = 0; b < batch; ++b) frozen_h[b] = 0;
     }
     // completion tags [2][batch][8] behind the scalars (same pinned block): tag q of slot s = outer iteration whose
     // scalar q is in scal_h[s]
     // behind them: the prox step sums [2][batch][FSTRIDE] of the optimistic launches
-    double *psum_h = reinterpret_cast<double *>(scal_h + 2 * (size_t)batch);
-    double *psum_hd = reinterpret_cast<double *>(scal_hd + 2 * (size_t)batch);
+    SalsaScal *init_h = scal_h + 2 * (size_t)batch, *init_hd = scal_hd + 2 * (size_t)batch;   // initial objective (own slot)
+    double *psum_h = reinterpret_cast<double *>(scal_h + 3 * (size_t)batch);
+    double *psum_hd = reinterpret_cast<double *>(scal_hd + 3 * (size_t)batch);
     double *tags_h = psum_h + 2 * (size_t)batch * FSTRIDE;
     double *tags_hd = psum_hd + 2 * (size_t)batch * FSTRIDE;
-    for (size_t i = 0; i < (size_t)2 * batch * SALSA_TAGS; ++i) tags_h[i] = 0.0;
+    double *init_tags_h = tags_h + 2 * (size_t)batch * SALSA_TAGS, *init_tags_hd = tags_hd + 2 * (size_t)batch * SALSA_TAGS;
+    for (size_t i = 0; i < (size_t)3 * batch * SALSA_TAGS; ++i) tags_h[i] = 0.0;
+    double *par_stage = init_tags_h + (size_t)batch * SALSA_TAGS;                             // parameter upload staging
+    {
+        // taps, mu and the prox threshold go up through pinned memory: no synchronisation (every call ends with one)
+        for (size_t q = 0; q < (size_t)batch * taille * taille; ++q) par_stage[q] = taps[q];
+        for (int b = 0; b < batch; ++b) {
+            par_stage[(size_t)batch * taille * taille + b] = mu[b];
+            par_stage[(size_t)batch * taille * taille + batch + b] = tau[b] / mu[b];   // threshold = tau/mu (:394)
+        }
+        SBTV_HIP(ctx, hipMemcpyAsync(par, par_stage, sizeof(double) * npar, hipMemcpyHostToDevice, ctx->stream));
+    }
+
     const double inv_scale = 1.0 / ((double)fp.n1 * N);
     const double parseval = 1.0 / ((double)M * N);
 
@@ -179,15 +183,24 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     } else {
         SBTV_HIP(ctx, hipMemcpyAsync(x, xi, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    // u = x ; bu = 0 ; g = x - bu = x (:392-393) ; duals zero (:418-421)
-    SBTV_HIP(ctx, hipMemcpyAsync(u, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    SBTV_HIP(ctx, hipMemcpyAsync(g, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    // u = x ; bu = 0 ; g = x - bu = x (:392-393) ; duals zero (:418-421).  From the zero start x = u = 0, g is not read
+    // before the first bookkeeping pass writes it (the first prox is not launched, see the loop), and neither start
+    // clears the duals: the first prox that is launched treats them as zero (cold start flag)
+    const bool zero_init = (opts->initialization == 0);
+    if (zero_init) {
+        SBTV_HIP(ctx, hipMemsetAsync(u, 0, sizeof(double) * cnt, ctx->stream));
+    } else {
+        SBTV_HIP(ctx, hipMemcpyAsync(u, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(g, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     SBTV_HIP(ctx, hipMemsetAsync(bu, 0, sizeof(double) * cnt, ctx->stream));
-    SBTV_TRY(prox_zero_duals(ctx, pp));
     SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
 
-    // ---- initial objective (:399-401): resid = y - A(x)
+    // ---- initial objective (:399-401): resid = y - A(x).  Its scalars go to their own pinned slot with completion tags
+    // and are read when the first outer iteration is processed: the loop is enqueued without waiting for them.
     std::vector<double> obj_prev(batch);
+    double *o4 = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
     {
         double *tvp = nullptr;
         int ntv = 0;
@@ -197,29 +210,49 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         a.H = Hs;
         a.Y = Ys;
         a.acc = acc;
-        SBTV_TRY(fft_cols_fwd(ctx, fp, x, nullptr, S));
+        if (zero_init) {
+            SBTV_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double2) * (size_t)batch * fp.s_img, ctx->stream));   // colFFT(0) = 0
+        } else {
+            SBTV_TRY(fft_cols_fwd(ctx, fp, x, nullptr, S));
+            SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));                                    // TV(0) = 0 otherwise
+        }
         SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
-        SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));
-        double *o4 = nullptr;
-        SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
         if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
-        Collect c{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0ull};
+        Collect c{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0ull, want_mse ? o4 : nullptr};
         hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (ProxCtrl *)nullptr,
-                           (unsigned long long)(uintptr_t)scal_d, (const int *)nullptr, 0, 0ull, 0.0);
-        SBTV_HIP(ctx, hipMemcpyAsync(scal_h, scal_d, sizeof(SalsaScal) * batch, hipMemcpyDeviceToHost, ctx->stream));
-        std::vector<double> h4((size_t)batch * 4, 0.0);
-        if (want_mse) SBTV_HIP(ctx, hipMemcpyAsync(h4.data(), o4, sizeof(double) * batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                           (unsigned long long)(uintptr_t)init_hd, (const int *)nullptr, 0,
+                           (unsigned long long)(uintptr_t)init_tags_hd, 1.0);
+        SBTV_HIP(ctx, hipGetLastError());
+        ctx->calls += batch;
+    }
+    bool init_read = false;
+    auto read_initial = [&]() -> int {
+        if (init_read) return 0;
+        init_read = true;
+        volatile const double *tg = init_tags_h;
+        for (unsigned spin = 0;; ++spin) {
+            bool ready = true;
+            for (int b = 0; b < batch && ready; ++b)
+                for (int i = 0; i < 8 && ready; ++i) ready = (tg[(size_t)b * SALSA_TAGS + i] == 1.0);
+            if (ready) break;
+            if (spin > 2000) {                                 // not there after a while: let the stream finish
+                SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                break;
+            }
+            struct timespec ts = {0, 5000};
+            nanosleep(&ts, nullptr);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         for (int b = 0; b < batch; ++b) {
             h_numA[b] += 1;
-            const double f0 = 0.5 * (scal_h[b].resid2 * parseval) + tau[b] * scal_h[b].tv_u;
+            const double f0 = 0.5 * (init_h[b].resid2 * parseval) + tau[b] * init_h[b].tv_u;
             obj_prev[b] = f0;
             if (objective) objective[(size_t)b * (maxiter + 1)] = f0;
             if (times) times[(size_t)b * (maxiter + 1)] = 0.0;
-            if (mses && want_mse) mses[(size_t)b * (maxiter + 1)] = h4[(size_t)b * 4] / (double)P;
+            if (mses && want_mse) mses[(size_t)b * (maxiter + 1)] = init_h[b].mse_num / (double)P;
         }
-        ctx->calls += batch;
-    }
+        return 0;
+    };
 
     std::vector<int> frozen(batch, 0), h_nouter(batch, 0);
     int active = batch;
@@ -275,10 +308,11 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         bool spec = false;
     } pend;
     const int nl_prox = prox_launches(pp, opts->TViters);
+    const bool zero_start = (opts->initialization == 0);
     auto make_collect = [&](int outer, bool spec) -> Collect {
         const int slot = outer & 1;
         return Collect{acc, nrb, nullptr, 0, postp, npb, spec ? pp.partials + (size_t)slot * pp.part_stride : nullptr, pp.fnblk,
-                       opts->TViters, (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSTRIDE)};
+                       opts->TViters, (unsigned long long)(uintptr_t)(psum_hd + (size_t)slot * batch * FSTRIDE), nullptr};
     };
     auto launch_collect = [&](int outer, bool spec, bool tagged) -> int {
         const int slot = outer & 1;
@@ -303,7 +337,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         const bool spec = spec_ok && outer >= 2;
         // the prox is bracketed by events on every 16th iteration only: an event record leaves the stream idle for
         // 5-6 us; sbtv_last_timing scales the sampled time to all iterations
-        const bool timed = eager && ((outer & 15) == 1);
+        const bool timed = eager && ((outer & 15) == 2);     // (2, 18, 34, ...: the first iteration may have no prox launch at all)
         slot_tagged[slot] = tagged;
         slot_spec[slot] = spec;
         double *xn = xbuf[slot];
@@ -329,8 +363,13 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         // host applies the rule over all TViters steps when it reads the iteration's scalars
         ProxPlan pps = pp;
         pps.partials = pp.partials + (size_t)slot * pp.part_stride;
-        SBTV_TRY(prox_iterate(ctx, pps, g, opts->TViters, u, false, spec, spec ? ((outer - 2) * nl_prox) & 1 : 0,
-                              side.nblocks ? &side : nullptr));
+        // From the zero start (INITIALIZATION 0: x = 0, bu = 0) the first prox input is g = 0: u = div p - g/lambda = 0,
+        // err = 0 <= tol, so chambolle_prox_TV_stop.m:131 stops at k = 1 with p = 0 and f = 0 - everything is already
+        // in place (u = 0, duals = 0) and no launch is needed; the host books the one iteration.
+        // (the duals are never cleared: the first prox that is launched starts cold)
+        if (!(zero_start && outer == 1))
+            SBTV_TRY(prox_iterate(ctx, pps, g, opts->TViters, u, outer == (zero_start ? 2 : 1), spec,
+                                  spec ? ((outer - 2) * nl_prox) & 1 : 0, side.nblocks ? &side : nullptr));
         if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
         prox_timed[slot] = timed;
         // (2) LS step in the spectral domain + residual energy (:434-444)
@@ -390,6 +429,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // host is normally one iteration ahead), yielding the core between polls.  No HIP call in the normal case: a
     // stream query makes the runtime append a marker packet, which costs the stream 5-6 us before the next kernel.
     // Only after 50 ms without the tags is the stream asked, so that a failed launch cannot leave the host waiting.
+    static const bool tag_spin_only = getenv("SBTV_TAG_SPIN") != nullptr;     // experiment: never sleep between polls
     auto wait_tags = [&](int slot, int outer) -> int {
         volatile const double *tg = tags_h + (size_t)slot * batch * SALSA_TAGS;
         const double want = (double)outer;
@@ -400,9 +440,9 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             for (int b = 0; b < batch && ready; ++b)
                 for (int i = 0; i < ntag && ready; ++i) ready = (tg[(size_t)b * SALSA_TAGS + i] == want);
             if (ready) break;
-            if (spin < 200) {
+            if (spin < 200 || tag_spin_only) {
                 __builtin_ia32_pause();
-                continue;
+                if (spin < 200 || (spin & 0xfffff) != 0) continue;     // (pure spinning still asks the stream now and then)
             }
             struct timespec ts = {0, 5000};
             nanosleep(&ts, nullptr);
@@ -422,6 +462,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // host side of outer iteration `outer`: traces + stopping rule (:444-482)
     auto process = [&](int outer) -> int {
         const int slot = outer & 1;
+        SBTV_TRY(read_initial());                                            // objective(1), mses(1): long there by now
         if (pend.valid && pend.outer == outer) SBTV_TRY(flush_pending());     // no later iteration took it along
         if (slot_tagged[slot]) SBTV_TRY(wait_tags(slot, outer));
         else SBTV_TRY(wait_event(ctx, ev_done[slot]));
@@ -442,6 +483,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             h_numA[b] += 1;
             h_nouter[b] = outer;
             double prox_k = s.pad;                   // exact launches: iterations booked by the stop-rule kernels
+            if (zero_start && outer == 1) prox_k = 1.0;   // the prox of a zero image: one iteration, not launched
             if (slot_spec[slot]) {
                 // optimistic launches: cont = (k < MaxIter) & (err > tol)  (chambolle_prox_TV_stop.m:131) over the steps
                 const double *ps = psum_h + ((size_t)slot * batch + b) * FSTRIDE;
@@ -509,17 +551,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         return sbtv_SALSA_v2(ctx, y, M, N, batch, taps, taille, tau, mu, &exact, true_x, x_init, x_out, objective, distance,
                              times, mses, numA, numAt, n_outer, flags);
     }
+    SBTV_TRY(read_initial());
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    {
-        float ms = 0.f;
-        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        ctx->timing[0] = ms;
-        // time inside the Chambolle launches: measured on the sampled iterations, scaled to all of them
-        ctx->timing[1] = prox_iters_timed > 0 ? ms_prox * ((double)prox_iters_run / (double)prox_iters_timed) : 0.0;
-        ctx->timing[2] = (double)prox_iters_run / batch;      // Chambolle iterations (image-averaged)
-        ctx->timing[3] = 40.0 * (double)P * (double)prox_iters_run;
-    }
     if (x_out) {
         // image b's result is the x written by ITS last processed iteration
         for (int b = 0; b < batch; ++b) {
@@ -528,7 +561,16 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                                          (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                                          ctx->stream));
         }
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the one synchronisation of the call
+    {
+        float ms = 0.f;
+        SBTV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->timing[0] = ms;
+        // time inside the Chambolle launches: measured on the sampled iterations, scaled to all of them
+        ctx->timing[1] = prox_iters_timed > 0 ? ms_prox * ((double)prox_iters_run / (double)prox_iters_timed) : 0.0;
+        ctx->timing[2] = (double)prox_iters_run / batch;      // Chambolle iterations (image-averaged)
+        ctx->timing[3] = 40.0 * (double)P * (double)prox_iters_run;
     }
     for (int b = 0; b < batch; ++b) {
         if (numA) numA[b] = h_numA[b];

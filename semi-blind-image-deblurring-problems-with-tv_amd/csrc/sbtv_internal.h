@@ -215,6 +215,7 @@ struct Collect {
     const double *ppart;
     int pnblk, psteps;
     unsigned long long psum_addr;   // [batch][FSTRIDE] step sums (pinned host memory, as an integer like `out`)
+    const double *mse0;     // initial objective only: pair_sums output [batch][4], element 0 -> mse_num (else null)
 };
 // A collector that rides on another kernel's launch: the first `nblocks` workgroups of that grid run its blocks
 // (a launch costs ~5 us however little it does; these blocks finish long before the host kernel's own work)

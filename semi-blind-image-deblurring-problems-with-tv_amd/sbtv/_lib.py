@@ -54,6 +54,12 @@ class sbtv_sapg_opts(C.Structure):
                 ("seed", C.c_ulonglong), ("chain_offset", C.c_int)]
 
 
+def vptr(a):
+    """void* of a NumPy array's data.  (numpy's `a.ctypes` builds a helper object on every access, ~25 us a time: with
+    seven output arrays that was a third of the fixed cost of a SALSA call.)  The caller keeps `a` alive."""
+    return C.c_void_p(a.__array_interface__["data"][0])
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 # sbtv_allreduce_dev_fn (flags & REDUCE_DEVICE): (user, device address of the 6 doubles, n, hipStream_t)
 ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
@@ -265,7 +271,7 @@ class Images:
                 raise ValueError("images must be (M,N) or (B,M,N)")
             self.B, self.M, self.N = a.shape
             self.buf = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))   # (B,N,M): column-major images
-            self.ptr = self.buf.ctypes.data_as(_P)
+            self.ptr = vptr(self.buf)
             self.flags = SBTV_HOST_PTRS
 
 
@@ -280,7 +286,7 @@ def empty_like_images(ref: Images):
     out.squeeze = getattr(ref, "squeeze", False)
     out.B, out.M, out.N = ref.B, ref.M, ref.N
     out.buf = np.empty((ref.B, ref.N, ref.M), dtype=np.float64)
-    out.ptr = out.buf.ctypes.data_as(_P)
+    out.ptr = vptr(out.buf)
     out.flags = SBTV_HOST_PTRS
     return out
 
@@ -313,4 +319,4 @@ def to_host(t):
 def dvec(v, n):
     """host double array of length n from a scalar or a sequence."""
     a = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)))
-    return a, a.ctypes.data_as(_P)
+    return a, vptr(a)

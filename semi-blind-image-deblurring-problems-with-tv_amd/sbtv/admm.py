@@ -18,7 +18,7 @@ _CORAL_OPTIONS = {"W", "WT", "P1", "P1T", "P2", "P2T", "PSI1", "PHI1", "TVINITIA
                   "TVINITIALIZATION2", "TVITERS2", "MU1", "MU2", "STOPCRITERION", "TOLERANCEA", "INNERITERS",
                   "MAXITERA", "INITIALIZATION", "TRUE_X", "AT", "VERBOSE", "LS", "SEED"}
 
-_vp = lambda a: a.ctypes.data_as(C.c_void_p)
+_vp = L.vptr
 
 
 def _common(y, A, opts, ctx, default_stop):

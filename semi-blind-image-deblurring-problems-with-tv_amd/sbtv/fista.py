@@ -46,7 +46,7 @@ def my_fista(b, A, AT, tau, L_, Phi, Psi, stopcriterion, tolerance, maxiters, tr
     nit = (C.c_int * B)()
     taps = A._cm(B)
     tau_a, tau_p = L.dvec(tau, B)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    vp = L.vptr
     import time
     t0 = time.perf_counter()
     ctx.check(ctx.lib.sbtv_fista_tv(ctx.h, bi.ptr, bi.M, bi.N, B, vp(taps), A.taille, tau_p, float(L_), Psi.maxiter,

@@ -85,7 +85,7 @@ class BlurOperator:
         out = L.empty_like_images(xi)
         taps = self._cm(xi.B)
         mu_a, mu_p = (None, None) if mu is None else L.dvec(mu, xi.B)
-        ctx.check(ctx.lib.sbtv_A_wrapper(ctx.h, taps.ctypes.data_as(C.c_void_p), self.taille, mu_p, xi.ptr, out.ptr,
+        ctx.check(ctx.lib.sbtv_A_wrapper(ctx.h, L.vptr(taps), self.taille, mu_p, xi.ptr, out.ptr,
                                          xi.M, xi.N, xi.B, int(mode), xi.flags), xi.flags)
         sq = (x.dim() == 2) if xi.torch else xi.squeeze
         return L.images_result(out, sq)

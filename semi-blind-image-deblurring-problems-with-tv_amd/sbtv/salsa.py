@@ -118,7 +118,7 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
     taps = A._cm(B)
     tau_a, tau_p = L.dvec(tau, B)
     mu_a, mu_p = L.dvec(mu, B)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    vp = L.vptr
     ctx.check(ctx.lib.sbtv_SALSA_v2(ctx.h, yi.ptr, M, N, B, vp(taps), A.taille, tau_p, mu_p, C.byref(so),
                                     ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr,
                                     vp(objective), vp(distance), vp(times), vp(mses) if ti else None,

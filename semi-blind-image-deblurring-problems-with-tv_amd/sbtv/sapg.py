@@ -39,7 +39,7 @@ def max_eigenval(A, At, params, im_size, tol, max_iter, verbose=0, x0=None, ctx=
     taps = A._cm(1)
     val = C.c_double(0.0)
     it = C.c_int(0)
-    ctx.check(ctx.lib.sbtv_max_eigenval(ctx.h, taps.ctypes.data_as(C.c_void_p), A.taille, xi.ptr, xi.M, xi.N,
+    ctx.check(ctx.lib.sbtv_max_eigenval(ctx.h, L.vptr(taps), A.taille, xi.ptr, xi.M, xi.N,
                                         float(tol), int(max_iter), C.byref(val), C.byref(it), xi.flags), xi.flags)
     if verbose:
         print(f"Norm = {val.value:e} ({it.value} iterations)")
@@ -140,14 +140,14 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
             if a.ndim == 3:
                 a = a[:, None]
             nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))     # column-major images
-            nz_ptr = nz_keep.ctypes.data_as(C.c_void_p)
+            nz_ptr = L.vptr(nz_keep)
     cb = L.ALLREDUCE_FN(reduce_fn) if reduce_fn is not None else L.ALLREDUCE_FN()
     xflags = L.SAPG_HOST_LOOP if host_loop else 0
     if reduce_dev_fn is not None:
         cb_dev = L.ALLREDUCE_DEV_FN(reduce_dev_fn)            # kept alive until the call returns
         cb = C.cast(cb_dev, L.ALLREDUCE_FN)
         xflags |= L.REDUCE_DEVICE
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    vp = L.vptr
     yptr = yi.ptr
     if share_gradients:
         # all chains sample ONE image: y is a single image, the batch size is the chain count
@@ -215,8 +215,8 @@ def _err_psf(kind, taille, ps, p_true, phi):
     pt = np.zeros(2)
     pt[:len(p_true)] = p_true
     out = np.zeros(ps.shape[1])
-    rc = lib.sbtv_err_psf(_KIND[kind], int(taille), tr.ctypes.data_as(C.c_void_p), int(ps.shape[1]),
-                          pt.ctypes.data_as(C.c_void_p), float(phi), out.ctypes.data_as(C.c_void_p))
+    rc = lib.sbtv_err_psf(_KIND[kind], int(taille), L.vptr(tr), int(ps.shape[1]),
+                          L.vptr(pt), float(phi), L.vptr(out))
     if rc != 0:
         raise L.SbtvError(rc, lib.sbtv_last_error(None).decode())
     return out
@@ -282,8 +282,8 @@ def myula(op, im=None, noise=None, ctx=None):
             if a.ndim == 3:
                 a = a[:, None]
             nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))
-            nz_ptr = nz_keep.ctypes.data_as(C.c_void_p)
-    ctx.check(ctx.lib.sbtv_myula(ctx.h, yi.ptr, M, N, B, taps.ctypes.data_as(C.c_void_p), A.taille,
+            nz_ptr = L.vptr(nz_keep)
+    ctx.check(ctx.lib.sbtv_myula(ctx.h, yi.ptr, M, N, B, L.vptr(taps), A.taille,
                                  float(_get(op, "lambda")), float(_get(op, "gamma")), keep[0][1], keep[1][1],
                                  int(_get(op, "samples")), int(_get(op, "chambolleit", 25)), int(_get(op, "seed", 1)),
                                  int(_get(op, "chain_offset", 0)), nz_ptr, xo.ptr, yi.flags), yi.flags)
