@@ -57,6 +57,19 @@ __device__ __forceinline__ double2 twid(const double2 *__restrict__ tw, int idx)
     if (INV) w.y = -w.y;
     return w;
 }
+// a twiddle table kept in LDS, one pad element per 16: the stage twiddles are read at power-of-two strides
+// ((r k) << SH), which would put the lanes of a group on the same banks of an unpadded table
+struct LdsTw {
+    const double2 *p;
+    static __host__ __device__ constexpr int elems(int n) { return n + (n >> 4); }
+    static __device__ __forceinline__ int idx(int i) { return i + (i >> 4); }
+};
+template <bool INV>
+__device__ __forceinline__ double2 twid(LdsTw tw, int idx) {
+    double2 w = tw.p[LdsTw::idx(idx)];
+    if (INV) w.y = -w.y;
+    return w;
+}
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
 __device__ __forceinline__ double2 mul_mi(double2 a) {
