@@ -273,7 +273,8 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_fwd_kernel(const double
                                                                      double2 *__restrict__ S,
                                                                      const double2 *__restrict__ tw_n1,
                                                                      const double2 *__restrict__ tw_M, int N,
-                                                                     const int *__restrict__ frozen) {
+                                                                     const int *__restrict__ frozen,
+                                                                     double *__restrict__ tvp) {
     constexpr int n = 1 << LOG2N, T = n / 8;
     constexpr int LDSN = n + (n >> 3);
     constexpr int MAXSEQ = (COLS_THREADS / T) > 0 ? (COLS_THREADS / T) : 1;
@@ -289,6 +290,35 @@ __global__ __launch_bounds__(COLS_THREADS) void fft_cols_fwd_kernel(const double
     double2 v[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) v[s] = xin[t + s * T];
+    if (tvp) {
+        // periodic isotropic TV of x (utils/TVnorm.m:2) on the way: tvp[b][workgroup] = this workgroup's share, summed in
+        // a fixed order.  Saves the callers (SAPG, FISTA) a separate TV launch over the same image.
+        constexpr int M = 2 * n;
+        const size_t cb = ((size_t)b * N + j) * M, cl = ((size_t)b * N + (j > 0 ? j - 1 : N - 1)) * M;
+        double up[8];
+        double2 ul[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int e = t + s * T;
+            up[s] = x[e > 0 ? cb + 2 * (size_t)e - 1 : cb + M - 1];
+            ul[s] = *reinterpret_cast<const double2 *>(x + cl + 2 * (size_t)e);
+        }
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double h0 = v[s].x - ul[s].x, v0 = v[s].x - up[s], h1 = v[s].y - ul[s].y, v1 = v[s].y - v[s].x;
+            a += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
+        }
+        const int nthr = blockDim.x;
+        lds[threadIdx.x] = a;
+        __syncthreads();
+        for (int stride = nthr >> 1; stride > 0; stride >>= 1) {
+            if ((int)threadIdx.x < stride) lds[threadIdx.x] += lds[threadIdx.x + stride];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) tvp[(size_t)b * gridDim.x + blockIdx.x] = lds[0];
+        __syncthreads();
+    }
     if (add) {
         const double2 *__restrict__ ain = reinterpret_cast<const double2 *>(add) + colbase;
 #pragma unroll
@@ -848,10 +878,10 @@ static inline int cols_nseq(const FftPlan &pl) {
 
 template <int L>
 static void launch_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S,
-                            const int *frozen) {
+                            const int *frozen, double *tvp) {
     const int nseq = cols_nseq(pl);
     hipLaunchKernelGGL(fft_cols_fwd_kernel<L>, dim3(pl.N / nseq, pl.batch), dim3(nseq * (pl.n1 / 8)), 0, ctx->stream,
-                       x, add, S, pl.tw_n1, pl.tw_M, pl.N, frozen);
+                       x, add, S, pl.tw_n1, pl.tw_M, pl.N, frozen, tvp);
 }
 template <int L>
 static void launch_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale,
@@ -882,29 +912,33 @@ static void launch_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2
         default: return fail(ctx, SBTV_ERR_SIZE, "unsupported FFT length"); \
     }
 
+// tvp != nullptr: also the periodic TV of x, as fft_cols_blocks(pl) partial sums per image (not with `add`, not on the
+// arbitrary-size path: callers check fft_cols_tv_ok)
+bool fft_cols_tv_ok(const FftPlan &pl) { return !pl.generic; }
 int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S,
-                   const int *frozen) {
+                   const int *frozen, double *tvp) {
+    if (tvp && (pl.generic || add)) return fail(ctx, SBTV_ERR_BADARG, "fft_cols_fwd: TV partials not available for this call");
     if (pl.generic) return any_cols_fwd(ctx, pl, x, add, S, frozen);
     if (pl.wave) {
         const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
         if (pl.n1 == 1024)
             hipLaunchKernelGGL((cols_fwd_wave_kernel<10, 16>), grid, block, 0, ctx->stream, x, add, S, pl.tw_n1, pl.tw_M,
-                               pl.N, frozen);
+                               pl.N, frozen, tvp);
         else
             hipLaunchKernelGGL((cols_fwd_wave_kernel<9, 8>), grid, block, 0, ctx->stream, x, add, S, pl.tw_n1, pl.tw_M,
-                               pl.N, frozen);
+                               pl.N, frozen, tvp);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
     const int L = ilog2(pl.n1);
-#define CALL(LL) launch_cols_fwd<LL>(ctx, pl, x, add, S, frozen)
+#define CALL(LL) launch_cols_fwd<LL>(ctx, pl, x, add, S, frozen, tvp)
     SBTV_DISPATCH_LOG2(L, CALL)
 #undef CALL
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
 int fft_cols_fwd(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S) {
-    return fft_cols_fwd_f(ctx, pl, x, add, S, nullptr);
+    return fft_cols_fwd_f(ctx, pl, x, add, S, nullptr, nullptr);
 }
 
 int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen) {

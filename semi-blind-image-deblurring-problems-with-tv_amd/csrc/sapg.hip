@@ -436,11 +436,16 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         a.Y = Bs;
         a.acc = acc;
         a.frozen = frozen;
-        SBTV_TRY(fft_cols_fwd_f(ctx, fp, x, nullptr, S, frozen));
-        SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
+        // TVnorm(x) rides on the forward column pass over the same image (no TV launch of its own)
         double *tvp = nullptr;
         int ntv = 0;
-        SBTV_TRY(tvnorm_partials(ctx, x, M, N, batch, &tvp, &ntv));
+        if (fft_cols_tv_ok(fp)) {
+            ntv = fft_cols_blocks(fp);
+            SBTV_TRY(ws_get_t(ctx, "fista.tvc", (size_t)batch * ntv, &tvp));
+        }
+        SBTV_TRY(fft_cols_fwd_f(ctx, fp, x, nullptr, S, frozen, tvp));
+        SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
+        if (!tvp) SBTV_TRY(tvnorm_partials(ctx, x, M, N, batch, &tvp, &ntv));
         hipLaunchKernelGGL(fista_collect_kernel, dim3(prox_was_spec ? 7 + prox_iters : 7, batch), dim3(256), 0, ctx->stream,
                            (const double *)acc, nrb, mom_partials, npb, (const double *)tvp, ntv, scal_hd, batch,
                            (const double *)pp.partials, pp.fnblk);
@@ -777,6 +782,9 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     };
     // spectral pass over X with the CURRENT spectra: accumulates ||AX-y||^2 and <dA_q X, AX-y>, and (if want_grad)
     // leaves grad = AT(AX - y) (unscaled by sigma^2)
+    double *tvc = nullptr;                    // TV partials of X from the forward column pass [batch][fft_cols_blocks]
+    const int ntvc = fft_cols_tv_ok(fp) ? fft_cols_blocks(fp) : 0;
+    if (ntvc) SBTV_TRY(ws_get_t(ctx, "sapg.tvc", (size_t)batch * ntvc, &tvc));
     auto operator_pass = [&](bool want_grad) -> int {
         RowsArgs a{};
         a.dir_fwd = 1;
@@ -788,7 +796,8 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         a.D2 = D2s;
         a.acc = acc;
         a.shared_spec = shared;
-        SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+        // TVnorm(X) (needed by the collector that follows every operator pass) rides on this column pass
+        SBTV_TRY(fft_cols_fwd_f(ctx, fp, X, nullptr, S, nullptr, tvc));
         SBTV_TRY(fft_rows(ctx, fp, S, want_grad ? S : nullptr, a));
         if (want_grad) SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         return 0;
@@ -796,9 +805,9 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     // TVnorm(X) partials + ONE collector launch that reduces them together with the accumulators of the last
     // operator pass straight into pinned host memory (no separate reductions, no copy kernel)
     auto collect_scalars = [&]() -> int {
-        double *tvp = nullptr;
-        int ntv = 0;
-        SBTV_TRY(tvnorm_partials(ctx, X, M, N, batch, &tvp, &ntv));
+        double *tvp = tvc;
+        int ntv = ntvc;
+        if (!tvp) SBTV_TRY(tvnorm_partials(ctx, X, M, N, batch, &tvp, &ntv));      // arbitrary-size path
         hipLaunchKernelGGL(sapg_collect_kernel, dim3(4, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
                            (const double *)tvp, ntv, scal_out, batch);
         SBTV_HIP(ctx, hipGetLastError());

@@ -320,7 +320,9 @@ int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad,
 int myula_plain_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
                      const double *sigma2_dev, double gam, double lamb, size_t P, int batch, const RngArgs *rng,
                      const ProxArm *arm);
-int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S, const int *frozen);
+int fft_cols_fwd_f(sbtv_ctx *ctx, const FftPlan &pl, const double *x, const double *add, double2 *S, const int *frozen,
+                   double *tvp = nullptr);
+bool fft_cols_tv_ok(const FftPlan &pl);
 int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen);
 
 #include "psf_taps.inc"   // psf_taps_point(): PSF formulas shared by host and device
