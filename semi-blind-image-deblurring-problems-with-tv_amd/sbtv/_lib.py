@@ -65,6 +65,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 REDUCE_DEVICE = 2        # include/sbtv.h SBTV_REDUCE_DEVICE
 SAPG_HOST_LOOP = 4       # include/sbtv.h SBTV_SAPG_HOST_LOOP
+FISTA_EXACT_PROX = 2     # include/sbtv.h SBTV_FISTA_EXACT_PROX
 
 _P = C.c_void_p
 _D = C.c_double

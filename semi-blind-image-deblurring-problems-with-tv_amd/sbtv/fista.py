@@ -23,9 +23,11 @@ class Psi_TV:
 
 
 def my_fista(b, A, AT, tau, L_, Phi, Psi, stopcriterion, tolerance, maxiters, true, verbose=0, ctx=None,
-             _zero_start=False):
+             _zero_start=False, exact_prox=False):
     """[x, objective, times, mses] = my_fista(b,A,AT,tau,L,Phi,Psi,stopcriterion,tolerance,maxiters,true,verbose)
-    (SALSA/my_fista.m:5-56).  A: sbtv.BlurOperator, AT: A.T, Phi: sbtv.TVnorm, Psi: sbtv.Psi_TV(K)."""
+    (SALSA/my_fista.m:5-56).  A: sbtv.BlurOperator, AT: A.T, Phi: sbtv.TVnorm, Psi: sbtv.Psi_TV(K).
+    exact_prox=True (extension, SBTV_FISTA_EXACT_PROX): a stop-rule kernel after every Chambolle launch instead of the
+    default optimistic launches (same result; the default repeats the call this way if the rule fires inside a prox)."""
     ctx = ctx or L.default_context()
     if not isinstance(A, BlurOperator) or not isinstance(AT, _Adjoint) or AT.op is not A:
         raise TypeError("A must be a sbtv.BlurOperator and AT its .T")
@@ -51,7 +53,7 @@ def my_fista(b, A, AT, tau, L_, Phi, Psi, stopcriterion, tolerance, maxiters, tr
     t0 = time.perf_counter()
     ctx.check(ctx.lib.sbtv_fista_tv(ctx.h, bi.ptr, bi.M, bi.N, B, vp(taps), A.taille, tau_p, float(L_), Psi.maxiter,
                                     int(stopcriterion), float(tolerance), K, 1 if _zero_start else 0, ti.ptr, xo.ptr,
-                                    vp(objective), vp(mses), nit, bi.flags), bi.flags)
+                                    vp(objective), vp(mses), nit, bi.flags | (L.FISTA_EXACT_PROX if exact_prox else 0)), bi.flags)
     wall = time.perf_counter() - t0
     sq = (b.dim() == 2) if bi.torch else bi.squeeze
     x = L.images_result(xo, sq)
