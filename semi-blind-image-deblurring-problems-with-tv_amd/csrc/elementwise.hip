@@ -40,6 +40,36 @@ int ew_blocks(size_t P) {
     return (int)nb;
 }
 
+// SALSA from the zero start (x = u = bu = 0, SALSA_v2.m:366-393): one pass clears the three images and leaves the
+// partial sums of the initial objective and mse (:399-401): resid = y - A(0) = y, so ||resid||^2 = sum y^2 (stored in
+// the units of the row-pass partials, i.e. of the unnormalised spectrum: x M N), TVnorm(0) = 0, mse(1) = sum true^2 / P.
+// accp [batch][3][G] (slot 0 is read), postp [batch][6][G] (slot 0 = mse numerator, slot 5 = TV, the others zero);
+// the collector reduces them in the usual fixed order.
+__global__ __launch_bounds__(EWB) void salsa_zero_start_kernel(const double *__restrict__ y, const double *__restrict__ tru,
+                                                                double *__restrict__ x, double *__restrict__ u,
+                                                                double *__restrict__ bu, double *__restrict__ accp,
+                                                                double *__restrict__ postp, size_t P, double scale) {
+    const int b = blockIdx.y;
+    __shared__ double red[2 * 4];
+    const size_t base = (size_t)b * P;
+    double acc[2] = {0, 0};
+    for (size_t q = (size_t)blockIdx.x * EWB + threadIdx.x; q < P; q += (size_t)gridDim.x * EWB) {
+        const double yv = y[base + q];
+        const double tv = tru ? tru[base + q] : 0.0;
+        acc[0] += yv * yv;
+        acc[1] += tv * tv;
+        x[base + q] = 0.0;
+        u[base + q] = 0.0;
+        bu[base + q] = 0.0;
+    }
+    ew_block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        const size_t G = gridDim.x;
+        for (int q = 0; q < 3; ++q) accp[((size_t)b * 3 + q) * G + blockIdx.x] = (q == 0) ? acc[0] * scale : 0.0;
+        for (int q = 0; q < 6; ++q) postp[((size_t)b * 6 + q) * G + blockIdx.x] = (q == 0) ? acc[1] : 0.0;
+    }
+}
+
 // generic two-array sums: partials[b][4][nb] = sum (a-b)^2, sum a^2, sum b^2, max a
 __global__ __launch_bounds__(EWB) void pair_sums_kernel(const double *__restrict__ a, const double *__restrict__ c,
                                                          double *__restrict__ partials, size_t P) {
@@ -241,6 +271,18 @@ int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int bat
                            nb, out4_dev + (size_t)b * 4 + 3);
     }
     SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int salsa_zero_start(sbtv_ctx *ctx, const double *y, const double *tru, double *x, double *u, double *bu, size_t P, int batch,
+                     double scale, double **accp, double **postp, int *nblk) {
+    const int G = ew_blocks(2 * P);
+    SBTV_TRY(ws_get_t(ctx, "ew.zero.acc", (size_t)batch * 3 * G, accp));
+    SBTV_TRY(ws_get_t(ctx, "ew.zero.post", (size_t)batch * 6 * G, postp));
+    hipLaunchKernelGGL(salsa_zero_start_kernel, dim3(G, batch), dim3(EWB), 0, ctx->stream, y, tru, x, u, bu, *accp, *postp, P,
+                       scale);
+    SBTV_HIP(ctx, hipGetLastError());
+    *nblk = G;
     return 0;
 }
 

@@ -168,8 +168,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // ---- initialisation (:366-381)
     double *x = xbuf[0];
     if (opts->initialization == 0) {
-        SBTV_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * cnt, ctx->stream));   // AT(zeros) == 0
-        ctx->calls += batch;
+        ctx->calls += batch;                                                      // AT(zeros) == 0: cleared below
     } else if (opts->initialization == 2) {
         // x = ATy = real(ifft2(conj(H) .* fft2(y)))
         RowsArgs a{};
@@ -187,13 +186,11 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // before the first bookkeeping pass writes it (the first prox is not launched, see the loop), and neither start
     // clears the duals: the first prox that is launched treats them as zero (cold start flag)
     const bool zero_init = (opts->initialization == 0);
-    if (zero_init) {
-        SBTV_HIP(ctx, hipMemsetAsync(u, 0, sizeof(double) * cnt, ctx->stream));
-    } else {
+    if (!zero_init) {
         SBTV_HIP(ctx, hipMemcpyAsync(u, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
         SBTV_HIP(ctx, hipMemcpyAsync(g, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipMemsetAsync(bu, 0, sizeof(double) * cnt, ctx->stream));
     }
-    SBTV_HIP(ctx, hipMemsetAsync(bu, 0, sizeof(double) * cnt, ctx->stream));
     SBTV_TRY(prox_reset(ctx, pp, thr_d, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
 
     // ---- initial objective (:399-401): resid = y - A(x).  Its scalars go to their own pinned slot with completion tags
@@ -202,23 +199,30 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     double *o4 = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.o4", (size_t)batch * 4, &o4));
     {
-        double *tvp = nullptr;
-        int ntv = 0;
-        RowsArgs a{};
-        a.dir_fwd = 1;
-        a.op = OP_RESID;
-        a.H = Hs;
-        a.Y = Ys;
-        a.acc = acc;
+        Collect c{};
         if (zero_init) {
-            SBTV_HIP(ctx, hipMemsetAsync(S, 0, sizeof(double2) * (size_t)batch * fp.s_img, ctx->stream));   // colFFT(0) = 0
+            // x = u = bu = 0: resid = y, TV(u) = 0, mse(1) = sum true^2 / P.  One pass clears the three images and leaves
+            // the partial sums (no transform of a zero image, no separate clears)
+            double *accz = nullptr, *postz = nullptr;
+            int nz = 0;
+            SBTV_TRY(salsa_zero_start(ctx, yd, want_mse ? td : nullptr, x, u, bu, P, batch, (double)M * (double)N, &accz, &postz,
+                                      &nz));
+            c = Collect{accz, nz, nullptr, 0, postz, nz, nullptr, 0, 0, 0ull, nullptr};
         } else {
+            double *tvp = nullptr;
+            int ntv = 0;
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.op = OP_RESID;
+            a.H = Hs;
+            a.Y = Ys;
+            a.acc = acc;
             SBTV_TRY(fft_cols_fwd(ctx, fp, x, nullptr, S));
-            SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));                                    // TV(0) = 0 otherwise
+            SBTV_TRY(tvnorm_partials(ctx, u, M, N, batch, &tvp, &ntv));
+            SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
+            if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
+            c = Collect{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0ull, want_mse ? o4 : nullptr};
         }
-        SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
-        if (want_mse) SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
-        Collect c{acc, nrb, tvp, ntv, nullptr, 0, nullptr, 0, 0, 0ull, want_mse ? o4 : nullptr};
         hipLaunchKernelGGL(salsa_collect_kernel, dim3(7, batch), dim3(256), 0, ctx->stream, c, (ProxCtrl *)nullptr,
                            (unsigned long long)(uintptr_t)init_hd, (const int *)nullptr, 0,
                            (unsigned long long)(uintptr_t)init_tags_hd, 1.0);

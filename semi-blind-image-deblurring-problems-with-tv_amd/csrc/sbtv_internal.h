@@ -310,6 +310,8 @@ int reduce_partials(sbtv_ctx *ctx, const double *partials, int nvec, int n, doub
 int ew_blocks(size_t P);
 // out4_dev[b*4 + {0,1,2,3}] = sum (a-c)^2, sum a^2, sum c^2, max a
 int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev);
+int salsa_zero_start(sbtv_ctx *ctx, const double *y, const double *tru, double *x, double *u, double *bu, size_t P, int batch,
+                     double scale, double **accp, double **postp, int *nblk);
 int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot, const ProxArm *arm = nullptr, int batch = 0);
 int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, double coef,
                    double *partials, size_t P, int batch, const int *frozen);
