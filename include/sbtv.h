@@ -85,7 +85,7 @@ int         sbtv_ctx_sync(sbtv_ctx *ctx);
 int         sbtv_callcounter_get(const sbtv_ctx *ctx, long long *calls);
 int         sbtv_callcounter_reset(sbtv_ctx *ctx);
 /* Timing of the most recent solver call, measured with HIP events on the
- * context stream: [0] total ms of the iteration loop, [1] ms inside the
+ * context stream: [0] total ms of the call on the device (set-up and iteration loop), [1] ms inside the
  * Chambolle iteration kernels, [2] number of Chambolle iteration launches,
  * [3] algorithmic bytes those launches moved (40 B/pixel/iteration). */
 int         sbtv_last_timing(const sbtv_ctx *ctx, double out[4]);

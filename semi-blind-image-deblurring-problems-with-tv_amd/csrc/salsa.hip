@@ -84,6 +84,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const int lag = (opts->speculate & 1) ? 1 : 0;
     const long long calls_at_entry = ctx->calls;
 
+    // start of the device-side clock of the call (sbtv_last_timing[0]): recorded while the stream is still idle - an event
+    // record between two kernels would cost the stream 5-6 us
+    SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+
     // ---- stage inputs
     const double *yd = nullptr, *td = nullptr, *xi = nullptr;
     SBTV_TRY(stage_in(ctx, "salsa.y", y, cnt, flags, &yd));
@@ -92,6 +96,13 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     double *xbuf[2] = {nullptr, nullptr}, *u = nullptr, *bu = nullptr, *g = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.x0", cnt, &xbuf[0]));
     SBTV_TRY(ws_get_t(ctx, "salsa.x1", cnt, &xbuf[1]));
+    // The last possible iteration (outer == maxiter) writes its x straight into a device-resident x_out: a solve that
+    // runs to MAXITERA then ends without the copy out of the double buffer (images that stop earlier are copied as
+    // before, after that write).  Not when x_out overlaps an input (an optimistic solve that has to be repeated reads
+    // them again) and not with captured iterations (their arguments are frozen).
+    auto overlaps_out = [&](const double *p) { return p && x_out && (p < x_out + cnt) && (x_out < p + cnt); };
+    const bool direct_last = x_out && (flags & SBTV_DEVICE_PTRS) && !graph_wanted(cnt) && !overlaps_out(yd) &&
+                             !overlaps_out(td) && !overlaps_out(xi);
     SBTV_TRY(ws_get_t(ctx, "salsa.u", cnt, &u));
     SBTV_TRY(ws_get_t(ctx, "salsa.bu", cnt, &bu));
     SBTV_TRY(ws_get_t(ctx, "salsa.g", cnt, &g));
@@ -283,7 +294,6 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         SBTV_HIP(ctx, hipEventCreate(&ev_p1[s]));
     }
     const auto t0 = std::chrono::steady_clock::now();
-    SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
 
     // enqueue the kernels of outer iteration `outer` (reads x = xbuf[(outer-1)&1] through g, writes
     // xbuf[outer&1]); `timed` brackets the prox with events (not inside a graph capture)
@@ -344,7 +354,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         const bool timed = eager && ((outer & 15) == 2);     // (2, 18, 34, ...: the first iteration may have no prox launch at all)
         slot_tagged[slot] = tagged;
         slot_spec[slot] = spec;
-        double *xn = xbuf[slot];
+        double *xn = (direct_last && outer == maxiter) ? x_out : xbuf[slot];
         const double *xprev = xbuf[slot ^ 1];
         // the previous iteration's collector: rides on this iteration's first (optimistic) launch, or gets its own
         SideJob side{};
@@ -560,6 +570,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     if (x_out) {
         // image b's result is the x written by ITS last processed iteration
         for (int b = 0; b < batch; ++b) {
+            if (direct_last && h_nouter[b] == maxiter) continue;        // already there
             const double *src = xbuf[h_nouter[b] & 1] + (size_t)b * P;
             SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, src, sizeof(double) * P,
                                          (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
