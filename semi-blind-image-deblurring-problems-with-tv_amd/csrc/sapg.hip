@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void fista_collect_kernel(const double *__rest
                                                             const double *__restrict__ mom, int npb,
                                                             const double *__restrict__ tvp, int ntv,
                                                             double *__restrict__ out, int batch,
-                                                            const double *__restrict__ ppart, int pnblk) {
+                                                            const double *__restrict__ ppart, int pnblk,
+                                                            unsigned long long tags_addr, double seq) {
+    // tags [batch][8 + FSTRIDE] (pinned host memory, passed as an integer like the SALSA collector's): tag q (or 8 + s
+    // for the step sums) = the iteration whose value `out` now holds; the host polls them instead of synchronising
+    double *__restrict__ tags = reinterpret_cast<double *>(tags_addr);
     __shared__ double red[4];
     const int q = blockIdx.x, b = blockIdx.y;
     if (q >= 7) {
@@ -74,7 +78,13 @@ __global__ __launch_bounds__(256) void fista_collect_kernel(const double *__rest
         for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
         __syncthreads();
-        if (threadIdx.x == 0) out[8 * (size_t)batch + (size_t)b * FSTRIDE + st] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) {
+            out[8 * (size_t)batch + (size_t)b * FSTRIDE + st] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (tags) {
+                __threadfence_system();
+                __hip_atomic_store(&tags[(size_t)b * (8 + FSTRIDE) + 8 + st], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         return;
     }
     const double *p;
@@ -99,7 +109,13 @@ __global__ __launch_bounds__(256) void fista_collect_kernel(const double *__rest
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[o] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        out[o] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tags) {
+            __threadfence_system();
+            __hip_atomic_store(&tags[(size_t)b * (8 + FSTRIDE) + q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- device-resident SAPG parameter update (SAPG_algorithm_Guassian.m:165-248 and twins) ------------------------
@@ -358,8 +374,12 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     const double *bd = nullptr, *td = nullptr;
     SBTV_TRY(stage_in(ctx, "fista.b", bimg, cnt, flags, &bd));
     SBTV_TRY(stage_in(ctx, "fista.true", true_x, cnt, flags, &td));
-    double *x = nullptr, *xold = nullptr, *y = nullptr, *grad = nullptr, *xfinal = nullptr;
-    SBTV_TRY(ws_get_t(ctx, "fista.x", cnt, &x));
+    // x is double-buffered by iteration parity: the host evaluates the stopping rule one iteration late while the next
+    // iteration already runs, and the iterate of a stopping iteration must still be intact then
+    double *xb[2] = {nullptr, nullptr}, *xold = nullptr, *y = nullptr, *grad = nullptr, *xfinal = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "fista.x", cnt, &xb[1]));
+    SBTV_TRY(ws_get_t(ctx, "fista.x2", cnt, &xb[0]));
+    double *x = xb[1];                                  // iterate 1 (the start)
     SBTV_TRY(ws_get_t(ctx, "fista.xold", cnt, &xold));
     SBTV_TRY(ws_get_t(ctx, "fista.y", cnt, &y));
     SBTV_TRY(ws_get_t(ctx, "fista.grad", cnt, &grad));
@@ -387,14 +407,23 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_TRY(ws_get_t(ctx, "fista.acc", (size_t)batch * 3 * nrb, &acc));
     SBTV_TRY(ws_get_t(ctx, "fista.momp", (size_t)batch * 3 * npb, &momp));
     SBTV_TRY(ws_get_t(ctx, "fista.o4", (size_t)batch * 4, &o4));
-    double *scal_h = nullptr, *scal_hd = nullptr;      // pinned [acc3 | mom3 | tv | pad] per image, host / device view
+    // pinned: two slots (iteration parity) of [acc3 | mom3 | tv | pad] per image + the step sums of an optimistic prox,
+    // then their completion tags, then the frozen flags for upload; host / device view
+    constexpr int FT = 8 + FSTRIDE;
+    const size_t slot_n = (size_t)FT * batch;
+    double *scal_base_h = nullptr, *scal_base_hd = nullptr;
+    int *frozen_h = nullptr;
     {
         void *pz = nullptr, *dp = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(double) * (8 + FSTRIDE) * batch, &pz));     // + the prox step sums of an optimistic prox
-        scal_h = static_cast<double *>(pz);
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * 4 * slot_n + sizeof(int) * batch, &pz));
+        scal_base_h = static_cast<double *>(pz);
         SBTV_HIP(ctx, hipHostGetDevicePointer(&dp, pz, 0));
-        scal_hd = static_cast<double *>(dp);
+        scal_base_hd = static_cast<double *>(dp);
+        for (size_t i = 0; i < 2 * slot_n; ++i) scal_base_h[2 * slot_n + i] = 0.0;      // tags: no iteration yet
+        frozen_h = reinterpret_cast<int *>(scal_base_h + 4 * slot_n);
+        for (int b = 0; b < batch; ++b) frozen_h[b] = 0;
     }
+    double *tags_base_h = scal_base_h + 2 * slot_n, *tags_base_hd = scal_base_hd + 2 * slot_n;
     const double inv_scale = 1.0 / ((double)fp.n1 * N), parseval = 1.0 / ((double)M * N);
     SBTV_TRY(psf_spectrum(ctx, fp, taps_d, taille, Hs));
     {
@@ -428,7 +457,8 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     // the whole call with exact launches (flag SBTV_FISTA_EXACT_PROX), so the result is always that of the exact rule.
     const bool prox_spec = !(flags & SBTV_FISTA_EXACT_PROX) && prox_spec_ok(pp, y, x, prox_iters);
     bool prox_was_spec = false;
-    auto objective_of_x = [&](const int *frozen, const double *mom_partials) -> int {
+    // objective / sums of iterate `xk` of iteration k -> pinned slot k & 1, tagged with k
+    auto objective_of_x = [&](const double *xk, int k, const int *frozen, const double *mom_partials) -> int {
         RowsArgs a{};
         a.dir_fwd = 1;
         a.op = OP_RESID;
@@ -443,38 +473,79 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             ntv = fft_cols_blocks(fp);
             SBTV_TRY(ws_get_t(ctx, "fista.tvc", (size_t)batch * ntv, &tvp));
         }
-        SBTV_TRY(fft_cols_fwd_f(ctx, fp, x, nullptr, S, frozen, tvp));
+        SBTV_TRY(fft_cols_fwd_f(ctx, fp, xk, nullptr, S, frozen, tvp));
         SBTV_TRY(fft_rows(ctx, fp, S, nullptr, a));
-        if (!tvp) SBTV_TRY(tvnorm_partials(ctx, x, M, N, batch, &tvp, &ntv));
+        if (!tvp) SBTV_TRY(tvnorm_partials(ctx, xk, M, N, batch, &tvp, &ntv));
+        const int slot = k & 1;
         hipLaunchKernelGGL(fista_collect_kernel, dim3(prox_was_spec ? 7 + prox_iters : 7, batch), dim3(256), 0, ctx->stream,
-                           (const double *)acc, nrb, mom_partials, npb, (const double *)tvp, ntv, scal_hd, batch,
-                           (const double *)pp.partials, pp.fnblk);
+                           (const double *)acc, nrb, mom_partials, npb, (const double *)tvp, ntv, scal_base_hd + slot * slot_n,
+                           batch, (const double *)pp.partials, pp.fnblk,
+                           (unsigned long long)(uintptr_t)(tags_base_hd + slot * slot_n), (double)k);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
-    auto fetch = [&]() -> int {
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // wait until the collector of iteration k has delivered every scalar: poll the tags in pinned memory (no HIP call in
+    // the normal case: a stream query would cost the stream a marker packet); ask the stream only after 50 ms
+    auto wait_tags = [&](int k, bool spec) -> int {
+        volatile const double *tg = tags_base_h + (size_t)(k & 1) * slot_n;
+        const double want = (double)k;
+        auto t_begin = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            bool ready = true;
+            for (int b = 0; b < batch && ready; ++b) {
+                for (int i = 0; i < 7 && ready; ++i) ready = (tg[(size_t)b * FT + i] == want);
+                for (int i = 0; spec && i < prox_iters && ready; ++i) ready = (tg[(size_t)b * FT + 8 + i] == want);
+            }
+            if (ready) break;
+            if (spin < 200) {
+                __builtin_ia32_pause();
+                continue;
+            }
+            struct timespec ts = {0, 5000};
+            nanosleep(&ts, nullptr);
+            if ((spin & 255) == 0 && std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(50)) {
+                const hipError_t e = hipStreamQuery(ctx->stream);
+                if (e == hipSuccess) {
+                    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    break;
+                }
+                if (e != hipErrorNotReady) return fail_hip(ctx, e, "hipStreamQuery", __FILE__, __LINE__);
+                t_begin = std::chrono::steady_clock::now();
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         return 0;
     };
     std::vector<double> obj_prev(batch, 0.0);
     std::vector<int> frozen(batch, 0), h_niter(batch, 1);
-    SBTV_TRY(objective_of_x(nullptr, nullptr));
+    SBTV_TRY(objective_of_x(x, 1, nullptr, nullptr));
     SBTV_TRY(pair_sums(ctx, x, td, P, batch, o4));
     {
         std::vector<double> h4((size_t)batch * 4);
         SBTV_HIP(ctx, hipMemcpyAsync(h4.data(), o4, sizeof(double) * 4 * batch, hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_TRY(fetch());
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double *sc = scal_base_h + slot_n;       // slot of iteration 1
         for (int b = 0; b < batch; ++b) {
-            const double f0 = 0.5 * (scal_h[(size_t)b * 3] * parseval) + tau[b] * scal_h[6 * (size_t)batch + b];
+            const double f0 = 0.5 * (sc[(size_t)b * 3] * parseval) + tau[b] * sc[6 * (size_t)batch + b];
             obj_prev[b] = f0;
             if (objective) objective[(size_t)b * maxiters] = f0;
             if (mses) mses[(size_t)b * maxiters] = h4[(size_t)b * 4] / (double)P;
         }
     }
-    double t = 1.0;
+    // The loop keeps one iteration in flight beyond the one the host is looking at (SBTV_FISTA_LAG=0: none): iteration
+    // k + 1 is enqueued before the scalars of iteration k are read, so the GPU never waits for the host.  If iteration k
+    // turns out to be an image's last, its iterate is still intact in its half of the double buffer (iteration k + 1
+    // wrote the other half), and whatever k + 1 did to that image is ignored.
+    static const int lag = [] {
+        const char *e = getenv("SBTV_FISTA_LAG");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    double t_enq = 1.0;
     int active = batch;
-    for (int k = 2; k <= maxiters && active > 0; ++k) {
-        const double t_old = t;
+    bool slot_spec[2] = {false, false};
+    auto enqueue = [&](int k) -> int {
+        const double t_old = t_enq;
+        double *xk = xb[k & 1];
         // y = y - (1/L) * AT(A(y) - b)                                   (:25)
         {
             RowsArgs a{};
@@ -499,28 +570,31 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         }
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
         prox_was_spec = prox_spec;
-        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, x, true, prox_spec));
-        t = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                     // :28
-        SBTV_TRY(fista_momentum(ctx, x, xold, y, td, (t_old - 1) / t, momp, P, batch, frozen_d));   // :29
-        SBTV_TRY(objective_of_x(frozen_d, momp));
-        SBTV_TRY(fetch());
-        if (prox_spec) {
+        slot_spec[k & 1] = prox_spec;
+        SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, xk, true, prox_spec));
+        t_enq = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                 // :28
+        SBTV_TRY(fista_momentum(ctx, xk, xold, y, td, (t_old - 1) / t_enq, momp, P, batch, frozen_d));   // :29
+        SBTV_TRY(objective_of_x(xk, k, frozen_d, momp));
+        return 0;
+    };
+    bool fired = false;
+    auto process = [&](int k) -> int {
+        SBTV_TRY(wait_tags(k, slot_spec[k & 1]));
+        const double *sc = scal_base_h + (size_t)(k & 1) * slot_n;
+        if (slot_spec[k & 1]) {
             // cont = (k < MaxIter) & (err > tol)  (chambolle_prox_TV_stop.m:131; tol 1e-3 as armed above)
-            bool fired = false;
             for (int b = 0; b < batch && !fired; ++b) {
                 if (frozen[b]) continue;
-                const double *ps = scal_h + 8 * (size_t)batch + (size_t)b * FSTRIDE;
+                const double *ps = sc + 8 * (size_t)batch + (size_t)b * FSTRIDE;
                 for (int kk = 1; kk < prox_iters && !fired; ++kk) fired = !(sqrt(ps[kk - 1]) > 1e-3);
             }
-            if (fired)
-                return sbtv_fista_tv(ctx, bimg, M, N, batch, taps, taille, tau, L, prox_iters, stopcriterion, tolerance, maxiters,
-                                     zero_start, true_x, x_out, objective, mses, n_iter, flags | SBTV_FISTA_EXACT_PROX);
+            if (fired) return 0;
         }
         bool changed = false;
         for (int b = 0; b < batch; ++b) {
             if (frozen[b]) continue;
-            const double f = 0.5 * (scal_h[(size_t)b * 3] * parseval) + tau[b] * scal_h[6 * (size_t)batch + b];
-            const double *mom = scal_h + 3 * (size_t)batch + (size_t)b * 3;
+            const double f = 0.5 * (sc[(size_t)b * 3] * parseval) + tau[b] * sc[6 * (size_t)batch + b];
+            const double *mom = sc + 3 * (size_t)batch + (size_t)b * 3;
             if (objective) objective[(size_t)b * maxiters + (k - 1)] = f;
             if (mses) mses[(size_t)b * maxiters + (k - 1)] = mom[0] / (double)P;
             h_niter[b] = k;
@@ -534,19 +608,39 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             obj_prev[b] = f;
             if (crit < tolerance) {                                      // :51
                 frozen[b] = 1;
+                frozen_h[b] = 1;
                 --active;
                 changed = true;
-                SBTV_HIP(ctx, hipMemcpyAsync(xfinal + (size_t)b * P, x + (size_t)b * P, sizeof(double) * P,
+                SBTV_HIP(ctx, hipMemcpyAsync(xfinal + (size_t)b * P, xb[k & 1] + (size_t)b * P, sizeof(double) * P,
                                              hipMemcpyDeviceToDevice, ctx->stream));
             }
         }
         if (changed && active > 0)
-            SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen.data(), sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
-        if (changed) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen_h, sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    };
+    {
+        int rc = 0, enq = 1, done = 1;
+        while (active > 0 && done < maxiters) {
+            while (rc == 0 && enq < maxiters && enq - done <= lag && active > 0) rc = enqueue(++enq);
+            if (rc != 0) break;
+            rc = process(++done);
+            if (rc != 0 || fired) break;
+        }
+        if (rc != 0) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return rc;
+        }
+        if (fired) {
+            // the stop rule fired inside an optimistic prox: repeat the whole call with exact launches
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return sbtv_fista_tv(ctx, bimg, M, N, batch, taps, taille, tau, L, prox_iters, stopcriterion, tolerance, maxiters,
+                                 zero_start, true_x, x_out, objective, mses, n_iter, flags | SBTV_FISTA_EXACT_PROX);
+        }
     }
     for (int b = 0; b < batch; ++b)
         if (!frozen[b])
-            SBTV_HIP(ctx, hipMemcpyAsync(xfinal + (size_t)b * P, x + (size_t)b * P, sizeof(double) * P,
+            SBTV_HIP(ctx, hipMemcpyAsync(xfinal + (size_t)b * P, xb[h_niter[b] & 1] + (size_t)b * P, sizeof(double) * P,
                                          hipMemcpyDeviceToDevice, ctx->stream));
     SBTV_TRY(stage_out_copy(ctx, x_out, xfinal, cnt, flags));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
