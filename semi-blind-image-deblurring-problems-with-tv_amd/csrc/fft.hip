@@ -961,6 +961,23 @@ int fft_cols_inv_f(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
+bool fft_cols_inv_step_ok(const FftPlan &pl) { return !pl.generic && pl.wave; }
+int fft_cols_inv_step(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *y, double scale, double alpha,
+                      const int *frozen) {
+    if (!fft_cols_inv_step_ok(pl)) return fail(ctx, SBTV_ERR_BADARG, "fft_cols_inv_step: size not on the wave-granular path");
+    ColsPost post;
+    post.ystep = y;
+    post.alpha = alpha;
+    const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
+    if (pl.n1 == 1024)
+        hipLaunchKernelGGL((cols_inv_wave_kernel<10, 16, 8>), grid, block, 0, ctx->stream, S, (double *)nullptr, pl.tw_n1,
+                           pl.tw_M, pl.N, scale, frozen, post);
+    else
+        hipLaunchKernelGGL((cols_inv_wave_kernel<9, 8, 8>), grid, block, 0, ctx->stream, S, (double *)nullptr, pl.tw_n1, pl.tw_M,
+                           pl.N, scale, frozen, post);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
 int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale) {
     return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
 }

@@ -44,6 +44,12 @@ __global__ __launch_bounds__(256) void sapg_collect_kernel(const double *__restr
     if (threadIdx.x == 0) out[(q < 3) ? (size_t)b * 3 + q : 3 * (size_t)batch + b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// images the host has frozen: their prox control block is parked (done = 1)
+__global__ void fista_park_kernel(ProxCtrl *__restrict__ ctrl, const int *__restrict__ frozen, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch && frozen[b]) ctrl[b].done = 1;
+}
+
 // FISTA scalars of one iteration in one launch: block (q, b): q < 3 rows-kernel accumulators [batch][3][nrb] ->
 // out[b*3+q]; q = 3..5 momentum-kernel sums [batch][3][npb] (may be null) -> out[3*batch + b*3 + (q-3)];
 // q = 6 periodic-TV partials [batch][ntv] -> out[6*batch + b].  `out` is the device view of pinned host memory.
@@ -543,6 +549,13 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     double t_enq = 1.0;
     int active = batch;
     bool slot_spec[2] = {false, false};
+    // fused gradient step (SBTV_FISTA_FUSED_STEP=0: the two-pass form, for A/B runs)
+    static const bool fused_wanted = [] {
+        const char *e = getenv("SBTV_FISTA_FUSED_STEP");
+        return !(e && e[0] == '0');
+    }();
+    const bool fused_step = fused_wanted && prox_spec && fft_cols_inv_step_ok(fp);
+    if (fused_step) SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
     auto enqueue = [&](int k) -> int {
         const double t_old = t_enq;
         double *xk = xb[k & 1];
@@ -558,6 +571,11 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             a.frozen = frozen_d;
             SBTV_TRY(fft_cols_fwd_f(ctx, fp, y, nullptr, S, frozen_d));
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
+            if (fused_step) {
+                // the gradient never reaches memory: the inverse column pass applies the step to y from its registers
+                // (optimistic prox launches do not consult the control blocks: armed once before the loop)
+                SBTV_TRY(fft_cols_inv_step(ctx, fp, S, y, inv_scale, 1.0 / L, frozen_d));
+            } else {
             SBTV_TRY(fft_cols_inv_f(ctx, fp, S, grad, inv_scale, frozen_d));
             // the gradient-step kernel also re-arms the control blocks of the cold-start prox that follows
             const ProxArm arm{pp.ctrl, lam_d, prox_iters, 1e-3, 0.249, frozen_d};
@@ -566,6 +584,7 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             } else {
                 SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt));
                 SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
+            }
             }
         }
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
@@ -615,8 +634,14 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
                                              hipMemcpyDeviceToDevice, ctx->stream));
             }
         }
-        if (changed && active > 0)
+        if (changed && active > 0) {
             SBTV_HIP(ctx, hipMemcpyAsync(frozen_d, frozen_h, sizeof(int) * batch, hipMemcpyHostToDevice, ctx->stream));
+            if (fused_step) {      // nothing re-arms the control blocks per iteration: park the frozen images' prox
+                hipLaunchKernelGGL(fista_park_kernel, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, pp.ctrl,
+                                   (const int *)frozen_d, batch);
+                SBTV_HIP(ctx, hipGetLastError());
+            }
+        }
         return 0;
     };
     {

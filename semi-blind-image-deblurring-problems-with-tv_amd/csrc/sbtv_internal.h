@@ -281,8 +281,17 @@ struct ColsPost {
     const double *tru = nullptr;
     const double *xprev = nullptr;
     double *partials = nullptr;      // [batch][6][fft_cols_blocks]
+    // gradient-step mode (fft_cols_inv_step): ystep <- ystep - alpha * x, x itself is not stored
+    double *ystep = nullptr;
+    double alpha = 0.0;
 };
 int fft_cols_blocks(const FftPlan &pl);
+// y <- y - alpha * (scale * colIFFT(S)) with the transform's output still in registers (my_fista.m:25: the gradient is
+// never written); only for the sizes of the wave-granular column pass (fft_cols_inv_step_ok), same bits as
+// fft_cols_inv_f followed by axpy
+bool fft_cols_inv_step_ok(const FftPlan &pl);
+int fft_cols_inv_step(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *y, double scale, double alpha,
+                      const int *frozen);
 int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
                       const ColsPost &post);
 struct RowsArgs {
