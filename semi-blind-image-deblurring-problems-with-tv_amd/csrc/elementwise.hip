@@ -136,8 +136,9 @@ __global__ __launch_bounds__(EWB) void axpy_kernel(double *__restrict__ y, const
         *reinterpret_cast<double2 *>(y + 2 * q) = yv;
     }
 }
-//   momentum  : y = x + c (x - x_old) ; x_old = x ; sums (x-true)^2, (x-x_old)^2, x^2   partials [batch][3][nb]
-__global__ __launch_bounds__(EWB) void fista_momentum_kernel(const double *__restrict__ x, double *__restrict__ xold,
+//   momentum  : y = x + c (x - x_old) ; sums (x-true)^2, (x-x_old)^2, x^2   partials [batch][3][nb]
+//   (x_old = x of my_fista.m:30 is not a copy: the caller double-buffers x, the previous iterate IS the other buffer)
+__global__ __launch_bounds__(EWB) void fista_momentum_kernel(const double *__restrict__ x, const double *__restrict__ xold,
                                                               double *__restrict__ y, const double *__restrict__ tru,
                                                               double c, double *__restrict__ partials, size_t P,
                                                               const int *__restrict__ frozen) {
@@ -152,7 +153,6 @@ __global__ __launch_bounds__(EWB) void fista_momentum_kernel(const double *__res
         const double2 xo = *reinterpret_cast<const double2 *>(xold + o);
         const double d0 = xv.x - xo.x, d1 = xv.y - xo.y;
         *reinterpret_cast<double2 *>(y + o) = make_double2(xv.x + c * d0, xv.y + c * d1);
-        *reinterpret_cast<double2 *>(xold + o) = xv;
         if (tru) {
             const double2 tv = *reinterpret_cast<const double2 *>(tru + o);
             const double e0 = xv.x - tv.x, e1 = xv.y - tv.y;
@@ -294,7 +294,7 @@ int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot, cons
     return 0;
 }
 
-int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, double coef,
+int fista_momentum(sbtv_ctx *ctx, const double *x, const double *xold, double *y, const double *tru, double coef,
                    double *partials, size_t P, int batch, const int *frozen) {
     hipLaunchKernelGGL(fista_momentum_kernel, dim3(ew_blocks(P), batch), dim3(EWB), 0, ctx->stream, x, xold, y, tru,
                        coef, partials, P, frozen);

@@ -382,11 +382,10 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_TRY(stage_in(ctx, "fista.true", true_x, cnt, flags, &td));
     // x is double-buffered by iteration parity: the host evaluates the stopping rule one iteration late while the next
     // iteration already runs, and the iterate of a stopping iteration must still be intact then
-    double *xb[2] = {nullptr, nullptr}, *xold = nullptr, *y = nullptr, *grad = nullptr, *xfinal = nullptr;
+    double *xb[2] = {nullptr, nullptr}, *y = nullptr, *grad = nullptr, *xfinal = nullptr;
     SBTV_TRY(ws_get_t(ctx, "fista.x", cnt, &xb[1]));
     SBTV_TRY(ws_get_t(ctx, "fista.x2", cnt, &xb[0]));
     double *x = xb[1];                                  // iterate 1 (the start)
-    SBTV_TRY(ws_get_t(ctx, "fista.xold", cnt, &xold));
     SBTV_TRY(ws_get_t(ctx, "fista.y", cnt, &y));
     SBTV_TRY(ws_get_t(ctx, "fista.grad", cnt, &grad));
     SBTV_TRY(stage_out_buf(ctx, "fista.xfinal", x_out, cnt, flags, &xfinal));
@@ -453,7 +452,6 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         SBTV_TRY(fft_cols_inv(ctx, fp, S, x, inv_scale));
     }
     SBTV_HIP(ctx, hipMemcpyAsync(y, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    SBTV_HIP(ctx, hipMemcpyAsync(xold, x, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
 
     // objective(k) = 0.5*||A x - b||^2 + tau*Phi(x) ; mses(k)   (:14-15, :31-33)
     // residual energy (Parseval) and TV partials of x, then ONE collector launch that reduces them (and the
@@ -592,7 +590,7 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
         slot_spec[k & 1] = prox_spec;
         SBTV_TRY(prox_iterate(ctx, pp, y, prox_iters, xk, true, prox_spec));
         t_enq = 0.5 * (1 + sqrt(1 + 4 * t_old * t_old));                 // :28
-        SBTV_TRY(fista_momentum(ctx, xk, xold, y, td, (t_old - 1) / t_enq, momp, P, batch, frozen_d));   // :29
+        SBTV_TRY(fista_momentum(ctx, xk, xb[(k - 1) & 1], y, td, (t_old - 1) / t_enq, momp, P, batch, frozen_d));   // :29-30
         SBTV_TRY(objective_of_x(xk, k, frozen_d, momp));
         return 0;
     };

@@ -322,7 +322,7 @@ int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int bat
 int salsa_zero_start(sbtv_ctx *ctx, const double *y, const double *tru, double *x, double *u, double *bu, size_t P, int batch,
                      double scale, double **accp, double **postp, int *nblk);
 int axpy(sbtv_ctx *ctx, double *y, const double *gr, double a, size_t Ptot, const ProxArm *arm = nullptr, int batch = 0);
-int fista_momentum(sbtv_ctx *ctx, const double *x, double *xold, double *y, const double *tru, double coef,
+int fista_momentum(sbtv_ctx *ctx, const double *x, const double *xold, double *y, const double *tru, double coef,
                    double *partials, size_t P, int batch, const int *frozen);
 // Z == nullptr: the normals are drawn in the kernel from `rng` (the numbers randn_kernel would have stored)
 int myula_step(sbtv_ctx *ctx, double *X, const double *prox, const double *grad, const double *Z,
