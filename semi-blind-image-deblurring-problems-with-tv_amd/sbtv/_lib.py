@@ -245,7 +245,7 @@ class Images:
     (use `to_device`) -> device pointer, no copy.
     """
 
-    def __init__(self, x, like=None):
+    def __init__(self, x, like=None, _fresh=False):
         self.torch = _is_torch(x)
         if self.torch:
             if x.dtype is not __import__("torch").float64:
@@ -258,7 +258,8 @@ class Images:
                 raise ValueError("device images must be column-major per image: use sbtv.to_device()")
             if not x.is_cuda:
                 raise ValueError("torch images must live on the GPU (numpy arrays are the host path)")
-            __import__("torch").cuda.current_stream(x.device).synchronize()   # producer kernels done
+            if not _fresh:          # (a buffer this module has just allocated has no producer)
+                __import__("torch").cuda.current_stream(x.device).synchronize()   # producer kernels done
             self.t = x
             self.B, self.M, self.N = B, M, N
             self.ptr = _P(x.data_ptr())
@@ -281,7 +282,7 @@ def empty_like_images(ref: Images):
     if ref.torch:
         import torch
         t = torch.empty((ref.B, ref.N, ref.M), dtype=torch.float64, device=ref.t.device).permute(0, 2, 1)
-        return Images(t)
+        return Images(t, _fresh=True)
     out = Images.__new__(Images)
     out.torch = False
     out.squeeze = getattr(ref, "squeeze", False)

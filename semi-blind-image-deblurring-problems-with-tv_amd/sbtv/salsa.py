@@ -58,7 +58,8 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
         raise L.SbtvError(-9, "(A^T A + \\mu I)^(-1) must be specified as a function handle.")  # :296
     if "MU" not in opts:
         mu = LS.mu
-    elif not np.allclose(np.asarray(mu, dtype=np.float64), np.asarray(LS.mu, dtype=np.float64), rtol=1e-6, atol=0.0):
+    elif (abs(mu - LS.mu) > 1e-6 * abs(LS.mu)) if (isinstance(mu, float) and isinstance(LS.mu, float)) else \
+            not np.allclose(np.asarray(mu, dtype=np.float64), np.asarray(LS.mu, dtype=np.float64), rtol=1e-6, atol=0.0):
         raise L.SbtvError(-9, "'MU' differs from the mu the 'LS' filter was built with: the GPU path has one mu "
                               "(run_Gaussian_demo.m:219-225 passes the same value to both)")
     if ("P" in opts) != ("PT" in opts):

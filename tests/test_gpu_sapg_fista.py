@@ -265,6 +265,28 @@ def test_fista_2048_moffat_device_resident(ctx, man512):
     assert o.PSNR(x, sbtv.to_host(xg)) > o.PSNR(x, st["y"])
 
 
+def test_fista_1024_batch_fused_gradient_step_matches_oracle(ctx, man512):
+    """1024 x 1024 (the 512-point instantiation of the wave-granular column pass): the inverse column pass applies the
+    gradient step y <- y - grad/L from its registers (my_fista.m:25), the host runs one iteration behind.  Two images in
+    one call, the first four iterations against the oracle, image by image."""
+    import sbtv
+    import sbtv_oracle as o
+    xs = [np.tile(man512, (2, 2)), np.tile(man512[::-1, ::-1], (2, 2)) * 0.7 + 20]
+    sts = [o.demo_setup("gaussian", xs[b], np.random.default_rng(5 + b).standard_normal(xs[b].shape), evMax=1.0) for b in range(2)]
+    p, model = sts[0]["p_true"], sts[0]["model"]
+    tau = [0.03 * st["sigma"] ** 2 for st in sts]
+    A = sbtv.BlurOperator(model.taps(*p))
+    y = np.stack([st["y"] for st in sts])
+    xg, obj, times, mses = sbtv.my_fista(y, A, A.T, tau, 1.0, sbtv.TVnorm, sbtv.Psi_TV(25), 1, 0.0, 4, np.stack(xs))
+    Psi = lambda v, th: o.chambolle_prox_TV_stop(v, lam=th, maxiter=25)[0]
+    for b in range(2):
+        ref = o.my_fista(sts[b]["y"], lambda v: model.A(v, *p), lambda v: model.AT(v, *p), tau[b], 1.0, o.TVnorm, Psi,
+                         1, 0.0, 4, xs[b])
+        np.testing.assert_allclose(obj[b], ref["objective"], rtol=1e-9)
+        np.testing.assert_allclose(mses[b], ref["mses"], rtol=1e-9)
+        assert np.max(np.abs(xg[b] - ref["x"])) < 1e-7
+
+
 @pytest.mark.parametrize("kind,params", [("gaussian", (1.0, 1.0)), ("moffat", (1.0, 5.0)), ("laplace", (1.0,))])
 def test_max_eigenval(ctx, kind, params):
     """evMax at the demos' parameters (run_Gaussian_demo.m:142, run_moffat_demo.m:140, run_laplace_demo.m:110)."""
