@@ -161,3 +161,51 @@ def test_sapg_device_loop_and_host_loop_give_the_same_bits_with_fixed_psf(ctx, s
         for key in ("thetas", "sigmas", "logPiTraceX", "gXTrace", "grad_theta", "grad_sigma", "theta_EB", "sigma_EB",
                     "Xlast_sample"):
             np.testing.assert_array_equal(np.asarray(dev[b][key]), np.asarray(host[b][key]), err_msg=key)
+
+
+def test_shortest_calls_device_resident(ctx):
+    """One and two iterations with device-resident images: the SALSA iteration numbered MAXITERA writes x straight into
+    x_out, FISTA evaluates its stopping rule one iteration late - the shortest calls are their corner cases.  Checked
+    against the same calls on host arrays (which go through the staging copies and the copy out of the double buffer)."""
+    import sbtv
+    M, N = 128, 96
+    x = synth_image(M, N, 3)
+    st = sbtv.demo_setup("gaussian", x, np.random.default_rng(8).standard_normal((M, N)), evMax=1.0)
+    A = sbtv.BlurOperator(sbtv.psf_family("gaussian", 7, (0.4, 0.3))[0])
+    mu, tau = 0.003, 0.03 * st["sigma"] ** 2
+    yd, xd = sbtv.to_device(st["y"]), sbtv.to_device(x)
+    for K in (1, 2, 3):
+        for init in (0, 2):
+            h = sbtv.SALSA_v2(st["y"], A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", x, "ToleranceA", -1.0,
+                              "MAXITERA", K, "TVINITIALIZATION", 1, "TViters", 10, "INITIALIZATION", init)
+            d = sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0,
+                              "MAXITERA", K, "TVINITIALIZATION", 1, "TViters", 10, "INITIALIZATION", init)
+            assert len(h[3]) == K + 1 == len(d[3])
+            np.testing.assert_array_equal(sbtv.to_host(d[0]), h[0])
+            np.testing.assert_array_equal(d[3], h[3])
+            np.testing.assert_array_equal(d[6], h[6])
+        hf = sbtv.my_fista(st["y"], A, A.T, tau, 1.0, sbtv.TVnorm, sbtv.Psi_TV(25), 1, 0.0, K, x)
+        df = sbtv.my_fista(yd, A, A.T, tau, 1.0, sbtv.TVnorm, sbtv.Psi_TV(25), 1, 0.0, K, xd)
+        assert len(hf[1]) == K == len(df[1])
+        np.testing.assert_array_equal(sbtv.to_host(df[0]), hf[0])
+        np.testing.assert_array_equal(df[1], hf[1])
+    # an output that overlaps an input falls back to the copy: x_out = the `true` image's memory
+    # (the Python mirror always allocates its own output, so this goes through the C-ABI directly)
+    import ctypes as C
+    import sbtv._lib as L
+    c = L.default_context()
+    so = L.sbtv_salsa_opts()
+    c.lib.sbtv_salsa_opts_default(C.byref(so))
+    so.maxiter, so.TViters, so.tolA = 3, 10, -1.0
+    ref = sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0, "MAXITERA", 3,
+                        "TVINITIALIZATION", 1, "TViters", 10)
+    yi, ti = L.Images(yd), L.Images(xd.clone())
+    taps = A._cm(1)
+    tau_a, tau_p = L.dvec(tau, 1)
+    mu_a, mu_p = L.dvec(mu, 1)
+    obj = np.zeros(4)
+    nout = (C.c_int * 1)()
+    c.check(c.lib.sbtv_SALSA_v2(c.h, yi.ptr, M, N, 1, L.vptr(taps), A.taille, tau_p, mu_p, C.byref(so), ti.ptr, None, ti.ptr,
+                                L.vptr(obj), None, None, None, None, None, nout, yi.flags), yi.flags)
+    np.testing.assert_array_equal(sbtv.to_host(ti.t[0]), sbtv.to_host(ref[0]))
+    np.testing.assert_array_equal(obj, ref[3])
