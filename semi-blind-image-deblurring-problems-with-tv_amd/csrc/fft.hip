@@ -740,13 +740,20 @@ __global__ void spec_unpack_kernel(const double2 *__restrict__ S, double2 *__res
 // of threads in flight matters more than the operation count, and up to 16 for large ones.
 constexpr int PSF_TMAX = 15;    // largest PSF size (sbtv.h)
 // TT = taille known at compile time (7: every demo of the reference) -> fully unrolled, no predicates; TT = 0: any size
+// up to three tap sets (the PSF and its parameter derivatives, SAPG with moving parameters) in ONE launch:
+// blockIdx.z = set * batch + image
+struct PsfSets {
+    const double *taps[3];
+    double2 *U[3];
+};
 template <int TT>
-__global__ __launch_bounds__(64) void psf_spectrum_kernel(const double *__restrict__ taps, int taille,
-                                                          double2 *__restrict__ U, int n1, int M, int N,
+__global__ __launch_bounds__(64) void psf_spectrum_kernel(PsfSets ps, int taille, int batch, int n1, int M, int N,
                                                           const double2 *__restrict__ tw_M,
                                                           const double2 *__restrict__ tw_N, int lch, int tiled) {
     constexpr int TN = TT ? TT : PSF_TMAX;
-    const int b = blockIdx.z;
+    const int set = blockIdx.z / batch, b = blockIdx.z - set * batch;
+    const double *__restrict__ taps = set == 0 ? ps.taps[0] : (set == 1 ? ps.taps[1] : ps.taps[2]);
+    double2 *__restrict__ U = set == 0 ? ps.U[0] : (set == 1 ? ps.U[1] : ps.U[2]);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > n1) return;
     const double *h = taps + (size_t)b * taille * taille;
@@ -1193,33 +1200,48 @@ int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U) 
     return 0;
 }
 
-int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U) {
+// spectra of `nsets` (<= 3) tap sets of the same size: one launch on the default layouts, else one call per set
+int psf_spectrum_sets(sbtv_ctx *ctx, const FftPlan &pl, const double *const *taps_dev, int taille, double2 *const *U, int nsets) {
     const int thr = 64;
     if (taille > PSF_TMAX) return fail(ctx, SBTV_ERR_PSF, "PSF larger than 15 x 15");
-    if (pl.generic) return any_psf_spectrum(ctx, pl, taps_dev, taille, U);
+    if (nsets < 1 || nsets > 3) return fail(ctx, SBTV_ERR_BADARG, "psf_spectrum_sets: 1..3 tap sets");
+    if (pl.generic) {
+        for (int q = 0; q < nsets; ++q) SBTV_TRY(any_psf_spectrum(ctx, pl, taps_dev[q], taille, U[q]));
+        return 0;
+    }
     const size_t elems = (size_t)(pl.n1 + 1) * pl.N * pl.batch;
     int lch = (int)(elems >> 19);                       // 512^2, 1024^2: 1;  2048^2: 4;  8 x 1024^2: 8
     lch = lch < 1 ? 1 : (lch > 16 ? 16 : lch);
     if (pl.u_ld) {
         const dim3 gridw((pl.N + thr - 1) / thr, (pl.n1 + 1 + lch - 1) / lch, pl.batch);
-        if (taille == 7)
-            hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<7>, gridw, dim3(thr), 0, ctx->stream, taps_dev, taille, U,
-                               pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
-        else
-            hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<0>, gridw, dim3(thr), 0, ctx->stream, taps_dev, taille, U,
-                               pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+        for (int q = 0; q < nsets; ++q) {
+            if (taille == 7)
+                hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<7>, gridw, dim3(thr), 0, ctx->stream, taps_dev[q], taille, U[q],
+                                   pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+            else
+                hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<0>, gridw, dim3(thr), 0, ctx->stream, taps_dev[q], taille, U[q],
+                                   pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+        }
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
-    const dim3 grid((pl.n1 + 1 + thr - 1) / thr, (pl.N + lch - 1) / lch, pl.batch);
+    PsfSets ps{};
+    for (int q = 0; q < 3; ++q) {
+        ps.taps[q] = taps_dev[q < nsets ? q : 0];
+        ps.U[q] = U[q < nsets ? q : 0];
+    }
+    const dim3 grid((pl.n1 + 1 + thr - 1) / thr, (pl.N + lch - 1) / lch, pl.batch * nsets);
     if (taille == 7)
-        hipLaunchKernelGGL(psf_spectrum_kernel<7>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
+        hipLaunchKernelGGL(psf_spectrum_kernel<7>, grid, dim3(thr), 0, ctx->stream, ps, taille, pl.batch, pl.n1, pl.M, pl.N,
                            pl.tw_M, pl.tw_N, lch, pl.u_tiled);
     else
-        hipLaunchKernelGGL(psf_spectrum_kernel<0>, grid, dim3(thr), 0, ctx->stream, taps_dev, taille, U, pl.n1, pl.M, pl.N,
+        hipLaunchKernelGGL(psf_spectrum_kernel<0>, grid, dim3(thr), 0, ctx->stream, ps, taille, pl.batch, pl.n1, pl.M, pl.N,
                            pl.tw_M, pl.tw_N, lch, pl.u_tiled);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
+}
+int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U) {
+    return psf_spectrum_sets(ctx, pl, &taps_dev, taille, &U, 1);
 }
 
 }  // namespace sbtv

@@ -804,7 +804,10 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     SBTV_TRY(ws_get_t(ctx, "sapg.S", (size_t)batch * fp.s_img, &S));
     SBTV_TRY(ws_get_t(ctx, "sapg.H", spec * nspec, &Hs));
     SBTV_TRY(ws_get_t(ctx, "sapg.D1", spec * nspec, &D1s));
-    SBTV_TRY(ws_get_t(ctx, "sapg.D2", spec * nspec, &D2s));
+    // a one-parameter PSF (Laplace) has one derivative spectrum: the second one the gradient pass reads IS the first
+    // (same memory: no third spectrum to compute, and its lines are already in the cache when the row pass asks again)
+    if (npar > 1) SBTV_TRY(ws_get_t(ctx, "sapg.D2", spec * nspec, &D2s));
+    else D2s = D1s;
     SBTV_TRY(ws_get_t(ctx, "sapg.Y", spec * nspec, &Ys));
     SBTV_TRY(ws_get_t(ctx, "sapg.S1", (size_t)nspec * fp.s_img, &S1));
     const size_t t2 = (size_t)taille * taille;
@@ -863,6 +866,12 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     std::vector<double> th_hist, s_hist, p_hist;      // running sums for the EB means
     std::vector<double> sum_th(batch, 0.0), sum_s(batch, 0.0), sum_p0(batch, 0.0), sum_p1(batch, 0.0);
 
+    // spectra of the taps and of their parameter derivatives, ONE launch for the two or three sets
+    auto spectra = [&]() -> int {
+        const double *tp[3] = {taps_d, d0_d, d1_d};
+        double2 *up[3] = {Hs, D1s, D2s};
+        return psf_spectrum_sets(ctx, fps, tp, taille, up, npar > 1 ? 3 : 2);
+    };
     // upload taps/derivative taps for the current parameters and rebuild the spectra
     std::vector<double> last_p0(nspec, NAN), last_p1(nspec, NAN);
     auto refresh_spectra = [&]() -> int {
@@ -881,10 +890,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         }
         SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));     // par_h may still be in flight
         SBTV_HIP(ctx, hipMemcpyAsync(par, par_h, sizeof(double) * 3 * t2 * nspec, hipMemcpyHostToDevice, ctx->stream));
-        SBTV_TRY(psf_spectrum(ctx, fps, taps_d, taille, Hs));
-        SBTV_TRY(psf_spectrum(ctx, fps, d0_d, taille, D1s));
-        if (npar > 1) SBTV_TRY(psf_spectrum(ctx, fps, d1_d, taille, D2s));
-        else SBTV_TRY(psf_spectrum(ctx, fps, d0_d, taille, D2s));
+        SBTV_TRY(spectra());
         return 0;
     };
     auto upload_lam_sigma = [&](const std::vector<double> &th) -> int {
@@ -990,9 +996,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         SBTV_HIP(ctx, hipMemcpyAsync(par, par_h, sizeof(double) * npar_all, hipMemcpyHostToDevice, ctx->stream));
         if (main_loop && params_move) {
             // spectra of the parameters moved by the previous iteration, then grad = AT(AX - y) with them
-            SBTV_TRY(psf_spectrum(ctx, fps, taps_d, taille, Hs));
-            SBTV_TRY(psf_spectrum(ctx, fps, d0_d, taille, D1s));
-            SBTV_TRY(psf_spectrum(ctx, fps, npar > 1 ? d1_d : d0_d, taille, D2s));
+            SBTV_TRY(spectra());
             RowsArgs a{};
             a.dir_fwd = 1;
             a.dir_inv = 1;
@@ -1091,9 +1095,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         // one iteration's device work; main = SAPG iteration (else warm-up), respec = new PSF spectra + gradF first
         auto enqueue_iteration = [&](bool main, bool respec, bool in_graph) -> int {
             if (respec) {
-                SBTV_TRY(psf_spectrum(ctx, fps, taps_d, taille, Hs));
-                SBTV_TRY(psf_spectrum(ctx, fps, d0_d, taille, D1s));
-                SBTV_TRY(psf_spectrum(ctx, fps, npar > 1 ? d1_d : d0_d, taille, D2s));
+                SBTV_TRY(spectra());
                 RowsArgs a{};
                 a.dir_fwd = 1;
                 a.dir_inv = 1;

@@ -312,6 +312,7 @@ int fft_rows_blocks(const FftPlan &pl);   // number of row blocks per image (acc
 int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U);
 // direct evaluation of the tap spectrum: U[(M/2+1) x N] per image from taps[batch][taille^2] (device)
 int psf_spectrum(sbtv_ctx *ctx, const FftPlan &pl, const double *taps_dev, int taille, double2 *U);
+int psf_spectrum_sets(sbtv_ctx *ctx, const FftPlan &pl, const double *const *taps_dev, int taille, double2 *const *U, int nsets);
 
 // ----------------------------- elementwise (elementwise.hip) ----------------
 // generic deterministic final reduction: out[b*nout + q] = sum_i partials[(b*nout+q)*n + i]
