@@ -1005,7 +1005,8 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             a.Y = Ys;
             a.acc = acc;
             a.shared_spec = shared;
-            SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+            // S still holds colFFT(X): the gradient-sums pass that ended the previous iteration wrote no spectrum, and X
+            // has not moved since - no second forward column pass
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
             SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         }
@@ -1104,7 +1105,8 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                 a.Y = Ys;
                 a.acc = acc;
                 a.shared_spec = shared;
-                SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+                // S still holds colFFT(X): the gradient-sums pass that ended the previous iteration wrote no spectrum, and X
+                // has not moved since - no second forward column pass
                 SBTV_TRY(fft_rows(ctx, fp, S, S, a));
                 SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
             }
@@ -1270,7 +1272,8 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             a.Y = Ys;
             a.acc = acc;
             a.shared_spec = shared;
-            SBTV_TRY(fft_cols_fwd(ctx, fp, X, nullptr, S));
+            // S still holds colFFT(X): the gradient-sums pass that ended the previous iteration wrote no spectrum, and X
+            // has not moved since - no second forward column pass
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
             SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
         }
