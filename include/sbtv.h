@@ -190,7 +190,10 @@ void sbtv_salsa_opts_default(sbtv_salsa_opts *o);
  *   mses[batch*(maxiter+1)]  (host arrays, any may be NULL; row b starts at b*(maxiter+1)
  *   resp. b*maxiter);  numA, numAt, n_outer: [batch] (host, may be NULL)
  *   Images in a batch iterate in lock-step; an image that met its stop rule is
- *   frozen (its x no longer changes) while the others continue. */
+ *   frozen (its x no longer changes) while the others continue.
+ *   x_out may overlap an input (then it is written once, at the end); a device-resident
+ *   x_out that overlaps none is also written by the iteration numbered maxiter, so its
+ *   contents are undefined until the call returns. */
 int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                   const double *taps, int taille, const double *tau, const double *mu,
                   const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
