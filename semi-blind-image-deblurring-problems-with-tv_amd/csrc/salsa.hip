@@ -351,7 +351,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         const bool spec = spec_ok && outer >= 2;
         // the prox is bracketed by events on every 32nd iteration only: an event record leaves the stream idle for
         // 5-6 us; sbtv_last_timing scales the sampled time to all iterations
-        const bool timed = eager && ((outer & 31) == 2);     // (2, 34, 66, ...: the first iteration may have no prox launch at all)
+        const bool timed = eager && ((outer & 31) == 4);     // (4, 36, 68, ...: warm-started proxes; the first one launched starts cold)
         slot_tagged[slot] = tagged;
         slot_spec[slot] = spec;
         double *xn = (direct_last && outer == maxiter) ? x_out : xbuf[slot];
