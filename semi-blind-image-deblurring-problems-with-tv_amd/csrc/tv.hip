@@ -200,17 +200,18 @@ __global__ __launch_bounds__(TVB) void chambolle_iter_kernel(const double *__res
 // ---------------------------------------------------------------------------
 // Temporally fused Chambolle kernel: up to FH iterations per launch.
 //
-// A workgroup (4 wave64) owns a REGION of FRI=128 rows x FRJ=64 columns that is
-// the CORE tile (116 x 52) plus a halo of FH=6 pixels on every side; one
-// iteration has a dependency radius of one pixel, so after s <= FH iterations
+// A workgroup (FNW wave64, default 8) owns a REGION of FRI=128 rows x FRJ = FNW*FCJ columns (default 8 x 4 = 32)
+// that is the CORE tile (116 x 21) plus a halo of FH=6 rows on either side and FHL=6 / FHJ=5 columns; one
+// iteration has a dependency radius of one pixel, so after s <= 5 iterations
 // the core is still exact.  The whole state of the region lives in REGISTERS:
-// lane l of wave w owns the row pair (2l, 2l+1) of the FCJ=16 columns
-// [16w, 16w+16) : px, py and g/lambda = 96 doubles per lane.  Row neighbours
+// lane l of wave w owns the row pair (2l, 2l+1) of the FCJ columns
+// [FCJ*w, FCJ*w + FCJ) : px, py = 16 doubles per lane; g/lambda is parked in LDS.  Row neighbours
 // come from the adjacent lanes through DPP wave shifts (no LDS, no memory);
-// column neighbours are in the same lane's registers except at the three
+// column neighbours are in the same lane's registers except at the FNW-1
 // wave seams, which exchange one column of u / py per iteration through LDS.
 // HBM traffic per launch is one read of (g,px,py) over the region and one
-// write of (px,py) over the core, for up to 6 iterations of work.
+// write of (px,py) over the core, for up to 5 iterations of work.
+// (Other geometries: SBTV_FUSED_VARIANT; measured in profiles/r02_chambolle_variants.md.)
 //
 // The stop rule of chambolle_prox_TV_stop.m:131 is evaluated after the launch
 // from per-iteration error partials; if it fired in the middle of a launch the
