@@ -29,11 +29,21 @@ static int launch_scale(sbtv_ctx *ctx, double *x, double a, size_t n) {
 // q < 3 of image b (||AX-y||^2 and the two <dA_p X, AX-y> sums, [batch][3][nrb]) or, for q = 3, the periodic-TV
 // partials ([batch][ntv]) and writes the total where the host reads it: out[b*3 + q] resp. out[3*batch + b].
 // `out` is the device view of pinned host memory, so no copy kernel follows.
+// Blocks q >= 4 (deferred stop rule of the multi-buffer prox, device-resident loop): block 4 + s totals the error
+// partials of Chambolle step s into out[4*batch + b*FSTRIDE + s]; the parameter-update kernel applies the rule.
 __global__ __launch_bounds__(256) void sapg_collect_kernel(const double *__restrict__ acc, int nrb,
                                                            const double *__restrict__ tvp, int ntv,
-                                                           double *__restrict__ out, int batch) {
+                                                           double *__restrict__ out, int batch,
+                                                           const double *__restrict__ ppart, int pnblk) {
     __shared__ double red[4];
     const int q = blockIdx.x, b = blockIdx.y;
+    if (q >= 4) {
+        if (threadIdx.x >= 64) return;
+        const int st = q - 4;
+        const double tot = mb_step_sum(ppart + ((size_t)b * FSTRIDE + st) * pnblk, pnblk, threadIdx.x);
+        if (threadIdx.x == 0) out[4 * (size_t)batch + (size_t)b * FSTRIDE + st] = tot;
+        return;
+    }
     const double *p = (q < 3) ? acc + ((size_t)b * 3 + q) * nrb : tvp + (size_t)b * ntv;
     const int n = (q < 3) ? nrb : ntv;
     double s = 0.0;
@@ -143,6 +153,10 @@ struct SapgDev {
     double *red;               // [6] shared-gradient sums (the all-reduce buffer)
     double *G;                 // [batch*4] per-chain gradients
     double *tr_theta, *tr_p, *tr_sigma, *tr_logpi, *tr_gx, *tr_grads, *tr_wu;   // device traces, layouts of sbtv.h
+    // deferred stop rule of the multi-buffer prox (null: the prox applies it itself): control blocks, the step sums the
+    // collector left behind the scalars, and the launch geometry (prox_k steps, launch l ran prox_base + (l < prox_extra))
+    ProxCtrl *pctrl;
+    int prox_k, prox_base, prox_extra;
 };
 enum { SAPG_PH_GRADS = 1, SAPG_PH_UPDATE = 2, SAPG_PH_WARMUP = 4 };
 
@@ -151,6 +165,17 @@ __global__ __launch_bounds__(256) void sapg_update_kernel(SapgDev u, int phase) 
     __shared__ double sf[225], se0[225], se1[225], ssum[3];
     const int B = u.batch, tid = threadIdx.x, t2 = u.taille * u.taille;
     double *lam_d = u.par + (size_t)3 * t2 * u.nspec, *sig_d = lam_d + B, *step_d = sig_d + B;
+    if (u.pctrl && (phase & (SAPG_PH_WARMUP | SAPG_PH_GRADS))) {
+        // the stop rule of the prox this iteration ran optimistically (chambolle_prox_TV_stop.m:131): one thread per chain
+        // books k / err and, if it stopped early, what the redo launch (which follows this kernel) has to repeat
+        for (int b = tid; b < B; b += 256) {
+            ProxCtrl c = u.pctrl[b];
+            if (!c.done) {
+                mb_apply_rule(c, u.scal + 4 * (size_t)B + (size_t)b * FSTRIDE, u.prox_k, u.prox_base, u.prox_extra);
+                u.pctrl[b] = c;
+            }
+        }
+    }
     if (phase & SAPG_PH_WARMUP) {
         // logPiTrace_WU(ii) of the warm-up iteration that just finished (:85); theta and sigma do not move here
         const int ii = u.it[1];
@@ -850,7 +875,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     int *it_d = nullptr;
     const size_t ntr = (size_t)batch * samples * 10 + (size_t)batch * (warmup > 0 ? warmup : 1);
     if (dev_loop) {
-        SBTV_TRY(ws_get_t(ctx, "sapg.scal", 4 * (size_t)batch, &scal_d));
+        SBTV_TRY(ws_get_t(ctx, "sapg.scal", (4 + (size_t)FSTRIDE) * batch, &scal_d));      // + the prox step sums
         SBTV_TRY(ws_get_t(ctx, "sapg.delta", (size_t)samples + 1, &delta_d));
         SBTV_TRY(ws_get_t(ctx, "sapg.red", 8, &red_d));
         SBTV_TRY(ws_get_t(ctx, "sapg.G", 4 * (size_t)batch, &G_d));
@@ -927,12 +952,13 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     };
     // TVnorm(X) partials + ONE collector launch that reduces them together with the accumulators of the last
     // operator pass straight into pinned host memory (no separate reductions, no copy kernel)
+    int collect_steps = 0;      // > 0: the collector also totals the step sums of the prox just run (deferred stop rule)
     auto collect_scalars = [&]() -> int {
         double *tvp = tvc;
         int ntv = ntvc;
         if (!tvp) SBTV_TRY(tvnorm_partials(ctx, X, M, N, batch, &tvp, &ntv));      // arbitrary-size path
-        hipLaunchKernelGGL(sapg_collect_kernel, dim3(4, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
-                           (const double *)tvp, ntv, scal_out, batch);
+        hipLaunchKernelGGL(sapg_collect_kernel, dim3(4 + collect_steps, batch), dim3(256), 0, ctx->stream, (const double *)acc, nrb,
+                           (const double *)tvp, ntv, scal_out, batch, (const double *)pp.partials, pp.fnblk);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     };
@@ -973,11 +999,21 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     // 1e-3 within the 25 iterations), so unlike SALSA / FISTA this path must handle them in place.
     const bool prox_mb = dev_loop && prox_spec_ok(pp, X, prox, op->chambolleit);
     if (prox_mb) SBTV_TRY(prox_reserve_pairs(ctx, &pp, prox_launches(pp, op->chambolleit) + 2));
+    // Deferred rule (default in the device-resident loop; SBTV_SAPG_DEFER=0: rule kernel + redo right after the launches):
+    // the prox output is not needed before the NEXT iteration's MYULA step, so the step sums are totalled by blocks of
+    // the collector, the rule is applied by the parameter-update kernel (both launched anyway) and only the (normally
+    // empty) redo launch follows them - one launch of 7-8 us less per iteration.
+    static const bool defer_wanted = [] {
+        const char *e = getenv("SBTV_SAPG_DEFER");
+        return !(e && e[0] == '0');
+    }();
+    const bool defer_rule = prox_mb && defer_wanted;
     auto do_prox = [&](bool armed) -> int {
         if (!armed) SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, op->chambolleit, 1e-3, 0.249, false, nullptr));
-        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox, true, (armed && prox_mb) ? 2 : 0));
+        SBTV_TRY(prox_iterate(ctx, pp, X, op->chambolleit, prox, true, (armed && prox_mb) ? (defer_rule ? 3 : 2) : 0));
         return 0;
     };
+    auto prox_redo = [&]() -> int { return prox_iterate(ctx, pp, X, op->chambolleit, prox, true, 4); };
 
     // ---- hipGraph replay (small images: ~25 launches of a few microseconds per iteration make the loop
     // launch-bound).  The graph body reads every per-iteration value (taps, lambda*theta, sigma^2, noise step)
@@ -1084,6 +1120,11 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         u.p_min1 = op->p_min[1]; u.p_max1 = op->p_max[1]; u.p_true0 = op->p_true[0]; u.p_true1 = op->p_true[1];
         u.s_lo = fmin(op->sigma2_min, op->sigma2_max); u.s_hi = fmax(op->sigma2_min, op->sigma2_max);
         u.sigma2_init = op->sigma2_init; u.phi = op->phi; u.step_base = (double)(warmup > 0 ? warmup - 1 : 0);
+        {
+            const int nlp = prox_launches(pp, op->chambolleit);
+            u.pctrl = defer_rule ? pp.ctrl : nullptr;
+            u.prox_k = op->chambolleit; u.prox_base = op->chambolleit / nlp; u.prox_extra = op->chambolleit % nlp;
+        }
         u.scal = scal_d; u.chain = chain_d; u.par = par; u.delta = delta_d; u.it = it_d; u.red = red_d; u.G = G_d;
         const size_t bs = (size_t)batch * samples;
         u.tr_theta = tr_d; u.tr_sigma = tr_d + bs; u.tr_logpi = tr_d + 2 * bs; u.tr_gx = tr_d + 3 * bs;
@@ -1113,13 +1154,22 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             SBTV_TRY(myula(in_graph));                                                             // :80-81 / :160-161
             SBTV_TRY(do_prox(true));                                                               // :82 / :162
             SBTV_TRY(operator_pass(main ? !params_move : true));                                   // G_w*, G_s, f  (:170-188)
+            collect_steps = defer_rule ? op->chambolleit : 0;
             SBTV_TRY(collect_scalars());                                                           // incl. g(X)  (:165)
-            if (!main) return update(SAPG_PH_WARMUP);
-            if (!(shared && reduce_dev)) return update(SAPG_PH_GRADS | SAPG_PH_UPDATE);
-            SBTV_TRY(update(SAPG_PH_GRADS));
-            if (reinterpret_cast<sbtv_allreduce_dev_fn>(reduce_fn)(reduce_user, red_d, 6, (void *)ctx->stream) != 0)
-                return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: reduce_fn failed");
-            return update(SAPG_PH_UPDATE);
+            collect_steps = 0;
+            if (!main) {
+                SBTV_TRY(update(SAPG_PH_WARMUP));
+            } else if (!(shared && reduce_dev)) {
+                SBTV_TRY(update(SAPG_PH_GRADS | SAPG_PH_UPDATE));
+            } else {
+                SBTV_TRY(update(SAPG_PH_GRADS));
+                if (reinterpret_cast<sbtv_allreduce_dev_fn>(reduce_fn)(reduce_user, red_d, 6, (void *)ctx->stream) != 0)
+                    return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: reduce_fn failed");
+                SBTV_TRY(update(SAPG_PH_UPDATE));
+            }
+            // the prox's stop rule has been applied by the update kernel: re-run the steps up to an early stop
+            if (defer_rule) SBTV_TRY(prox_redo());
+            return 0;
         };
         // graph replay (opt-in, small images): the body takes everything from device memory, so launches need no
         // staging; a run with an in-stream collective launches eagerly (the collective is enqueued by the caller's code)

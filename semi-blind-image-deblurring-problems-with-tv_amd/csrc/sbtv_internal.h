@@ -28,6 +28,57 @@ struct ProxCtrl {
     double tau;
 };
 
+// ---- stop rule of a multi-buffer optimistic prox (prox_iterate modes 2-4): shared by chambolle_mb_ctrl_kernel (tv.hip)
+// and by the SAPG collector / parameter-update kernels, which can apply it on their way (sapg.hip).
+// Sum of the error partials of one step by ONE wave, in the fixed order of the control kernels (lane-strided over
+// chunks of 1024 tiles, then the xor tree).
+__device__ __forceinline__ double mb_step_sum(const double *__restrict__ p, int nblk, int lane) {
+    double acc = 0.0;
+    for (int q0 = 0; q0 < nblk; q0 += 64 * 16) {
+        double v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + r * 64 + lane;
+            v[r] = (q < nblk) ? p[q] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += v[r];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    return acc;
+}
+// cont = (k < MaxIter) & (err > tol)  (chambolle_prox_TV_stop.m:131) over the `total` step sums of a prox whose launch l
+// ran base + (l < extra) steps.  Stopped at the last step: the f the last launch wrote stands (f_valid).  Stopped at an
+// earlier k: `cur` = the dual buffer of the launch boundary before k, `redo` = the steps from there to k (the redo
+// launch re-runs them and rewrites f).
+__device__ __forceinline__ void mb_apply_rule(ProxCtrl &c, const double *tots, int total, int base, int extra) {
+    int k = total;
+    for (int st = 0; st < total; ++st) {
+        if (!((st + 1 < total) && (sqrt(tots[st]) > c.tol))) {
+            k = st + 1;
+            break;
+        }
+    }
+    c.k = k;
+    c.err = sqrt(tots[k - 1]);
+    c.done = 1;
+    if (k == total) {
+        c.redo = 0;
+        c.f_valid = 1;
+    } else {
+        int l = 0, start = 0;
+        for (;; ++l) {
+            const int len = base + (l < extra ? 1 : 0);
+            if (k <= start + len) break;
+            start += len;
+        }
+        c.cur = l;                              // dual buffer at the launch boundary before k (0 = the cold start)
+        c.redo = k - start;
+        c.f_valid = 0;
+    }
+}
+
 // Scalars one SALSA outer iteration hands back to the host (per image).
 struct SalsaScal {
     double resid2;   // ||y - A x||^2 (Parseval)

@@ -481,31 +481,7 @@ __global__ __launch_bounds__(64 * FSMAX) void chambolle_mb_ctrl_kernel(ProxCtrl 
     if (threadIdx.x != 0) return;
     ProxCtrl c = ctrl[b];
     if (c.done) return;                         // parked image
-    int k = total;
-    for (int st = 0; st < total; ++st) {
-        if (!((st + 1 < total) && (sqrt(tots[st]) > c.tol))) {
-            k = st + 1;
-            break;
-        }
-    }
-    c.k = k;
-    c.err = sqrt(tots[k - 1]);
-    c.done = 1;
-    if (k == total) {
-        c.redo = 0;
-        c.f_valid = 1;
-    } else {
-        // launch l covers steps [start_l, start_l + len_l): find the one holding step k
-        int l = 0, start = 0;
-        for (;; ++l) {
-            const int len = base + (l < extra ? 1 : 0);
-            if (k <= start + len) break;
-            start += len;
-        }
-        c.cur = l;                              // dual buffer at the launch boundary before k (0 = the cold start)
-        c.redo = k - start;
-        c.f_valid = 0;
-    }
+    mb_apply_rule(c, tots, total, base, extra);
     ctrl[b] = c;
 }
 
@@ -818,8 +794,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                  int spec_parity, const SideJob *side) {
     // spec: 0 exact launches, 1 optimistic ping-pong launches (warm or cold; the caller checks the rule), 2 multi-buffer
     // optimistic launches of a cold prox with the rule applied and honoured right after them (see the kernels, bit 3)
+    // 3 / 4: the multi-buffer mode in two parts for a caller that applies the rule itself between them (mb_apply_rule
+    // on the step sums; the SAPG loop does it in kernels it launches anyway): 3 = the launches only, 4 = the redo only
     const bool spec_cur = spec != 0;
-    const bool mb = spec == 2;
+    const bool mb = spec >= 2;
+    const bool mb_main = spec != 4, mb_ctrl = spec == 2, mb_redo = spec == 2 || spec == 4;
     if (mb && (!cold || !f_out || (size_t)pl.pairs < (size_t)prox_launches(pl, maxiter) + 2))
         return fail(ctx, SBTV_ERR_BADARG, "prox_iterate: the multi-buffer mode needs a cold prox with f output and prox_reserve_pairs()");
     const dim3 grid(pl.tiles_i, pl.tiles_j, pl.batch);
@@ -932,12 +911,12 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             return 0;
         };
         const int wf = f_out ? 1 : 0;
-        for (int l = 0; l < nl; ++l) SBTV_TRY(launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0));
-        if (mb) {
+        if (mb_main)
+            for (int l = 0; l < nl; ++l) SBTV_TRY(launch_fused(base + (l < extra ? 1 : 0), 0, (l == nl - 1) ? wf : 0));
+        if (mb && mb_ctrl)
             hipLaunchKernelGGL(chambolle_mb_ctrl_kernel, dim3(pl.batch), dim3(64 * FSMAX), 0, ctx->stream, pl.ctrl, pl.partials,
                                pl.fnblk, maxiter, base, extra);
-            SBTV_TRY(launch_fused(0, 1, wf));                    // re-runs the steps up to an early stop (normally empty)
-        }
+        if (mb && mb_redo) SBTV_TRY(launch_fused(0, 1, wf));     // re-runs the steps up to an early stop (normally empty)
         if (!spec_cur) SBTV_TRY(launch_fused(0, 1, wf));     // redo pass; doubles as the finish-only pass when f is not valid yet
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
