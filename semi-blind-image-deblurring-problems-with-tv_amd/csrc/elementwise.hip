@@ -199,8 +199,8 @@ __global__ __launch_bounds__(EWB) void myula_step_kernel(double *__restrict__ X,
         const double2 zv = Z ? *reinterpret_cast<const double2 *>(Z + o)
                              : philox_normal_pair(q, step, rng.chain0 + (unsigned)b, rng.seed);
         double2 r;
-        r.x = fabs(((xv.x + gam * (pv.x - xv.x) / lamb) - gam * (gv.x / s2)) + sq2g * zv.x);
-        r.y = fabs(((xv.y + gam * (pv.y - xv.y) / lamb) - gam * (gv.y / s2)) + sq2g * zv.y);
+        r.x = myula_nocontract(xv.x, pv.x, gv.x, 1.0, zv.x, gam, lamb, s2, sq2g);
+        r.y = myula_nocontract(xv.y, pv.y, gv.y, 1.0, zv.y, gam, lamb, s2, sq2g);
         *reinterpret_cast<double2 *>(X + o) = r;
     }
 }

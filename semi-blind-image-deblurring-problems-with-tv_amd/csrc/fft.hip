@@ -985,6 +985,31 @@ int fft_cols_inv_step(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
+int fft_cols_inv_myula(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double scale, double *X, const double *prox,
+                       const double *Z, const double *sigma2_dev, double gam, double lamb, const RngArgs *rng,
+                       const ProxArm *arm) {
+    if (!fft_cols_inv_step_ok(pl)) return fail(ctx, SBTV_ERR_BADARG, "fft_cols_inv_myula: size not on the wave-granular path");
+    if (!Z && !rng) return fail(ctx, SBTV_ERR_BADARG, "fft_cols_inv_myula: neither a noise array nor generator arguments");
+    ColsPost post;
+    post.ystep = X;
+    post.mprox = prox;
+    post.mZ = Z;
+    post.msig2 = sigma2_dev;
+    post.mgam = gam;
+    post.mlamb = lamb;
+    post.msq2g = sqrt(2 * gam);
+    if (rng) post.mrng = *rng;
+    if (arm) post.marm = *arm;
+    const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
+    if (pl.n1 == 1024)
+        hipLaunchKernelGGL((cols_inv_wave_kernel<10, 16, 16>), grid, block, 0, ctx->stream, S, (double *)nullptr, pl.tw_n1,
+                           pl.tw_M, pl.N, scale, (const int *)nullptr, post);
+    else
+        hipLaunchKernelGGL((cols_inv_wave_kernel<9, 8, 16>), grid, block, 0, ctx->stream, S, (double *)nullptr, pl.tw_n1, pl.tw_M,
+                           pl.N, scale, (const int *)nullptr, post);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
 int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale) {
     return fft_cols_inv_f(ctx, pl, S, x, scale, nullptr);
 }

@@ -933,6 +933,22 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     double *tvc = nullptr;                    // TV partials of X from the forward column pass [batch][fft_cols_blocks]
     const int ntvc = fft_cols_tv_ok(fp) ? fft_cols_blocks(fp) : 0;
     if (ntvc) SBTV_TRY(ws_get_t(ctx, "sapg.tvc", (size_t)batch * ntvc, &tvc));
+    // The gradient's only reader is the MYULA step.  On the sizes of the wave-granular column pass its spectrum stays in S
+    // and the inverse column pass that would store it runs as part of that step instead (fft_cols_inv_myula: no gradient
+    // array, one launch less); SBTV_SAPG_FUSED_MYULA=0 or any other size: inverse pass here, element-wise step later.
+    static const bool fuse_wanted = [] {
+        const char *e = getenv("SBTV_SAPG_FUSED_MYULA");
+        return !(e && e[0] == '0');
+    }();
+    const bool fuse_myula = fuse_wanted && fft_cols_inv_step_ok(fp);
+    bool grad_in_S = false;               // S holds the spectrum of the gradient the next MYULA step needs
+    auto gradient_from_S = [&]() -> int {
+        if (fuse_myula) {
+            grad_in_S = true;
+            return 0;
+        }
+        return fft_cols_inv(ctx, fp, S, grad, inv_scale);
+    };
     auto operator_pass = [&](bool want_grad) -> int {
         RowsArgs a{};
         a.dir_fwd = 1;
@@ -947,7 +963,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         // TVnorm(X) (needed by the collector that follows every operator pass) rides on this column pass
         SBTV_TRY(fft_cols_fwd_f(ctx, fp, X, nullptr, S, nullptr, tvc));
         SBTV_TRY(fft_rows(ctx, fp, S, want_grad ? S : nullptr, a));
-        if (want_grad) SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+        if (want_grad) SBTV_TRY(gradient_from_S());
         return 0;
     };
     // TVnorm(X) partials + ONE collector launch that reduces them together with the accumulators of the last
@@ -983,12 +999,16 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     // The step kernel also re-arms the prox control blocks for the cold-start prox that always follows it.
     const ProxArm arm{pp.ctrl, lam_d, op->chambolleit, 1e-3, 0.249, nullptr};
     auto myula = [&](bool in_graph) -> int {
+        const bool fused = grad_in_S;
+        grad_in_S = false;
         if (noise) {
             SBTV_TRY(next_noise());
+            if (fused) return fft_cols_inv_myula(ctx, fp, S, inv_scale, X, prox, Z, sig_d, gam, lamb, nullptr, &arm);
             return myula_step(ctx, X, prox, grad, Z, sig_d, gam, lamb, P, batch, nullptr, &arm);
         }
         const RngArgs r{op->seed, (unsigned)noise_step, (unsigned)op->chain_offset, in_graph ? step_d : nullptr};
         if (!in_graph) ++noise_step;
+        if (fused) return fft_cols_inv_myula(ctx, fp, S, inv_scale, X, prox, nullptr, sig_d, gam, lamb, &r, &arm);
         return myula_step(ctx, X, prox, grad, nullptr, sig_d, gam, lamb, P, batch, &r, &arm);
     };
     // prox = chambolle(X, lambda*theta, cold start); armed: the MYULA step before it has reset the control blocks
@@ -1044,7 +1064,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             // S still holds colFFT(X): the gradient-sums pass that ended the previous iteration wrote no spectrum, and X
             // has not moved since - no second forward column pass
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
-            SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+            SBTV_TRY(gradient_from_S());
         }
         SBTV_TRY(myula(true));
         SBTV_TRY(do_prox(true));
@@ -1149,7 +1169,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                 // S still holds colFFT(X): the gradient-sums pass that ended the previous iteration wrote no spectrum, and X
                 // has not moved since - no second forward column pass
                 SBTV_TRY(fft_rows(ctx, fp, S, S, a));
-                SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+                SBTV_TRY(gradient_from_S());
             }
             SBTV_TRY(myula(in_graph));                                                             // :80-81 / :160-161
             SBTV_TRY(do_prox(true));                                                               // :82 / :162
@@ -1325,7 +1345,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
             // S still holds colFFT(X): the gradient-sums pass that ended the previous iteration wrote no spectrum, and X
             // has not moved since - no second forward column pass
             SBTV_TRY(fft_rows(ctx, fp, S, S, a));
-            SBTV_TRY(fft_cols_inv(ctx, fp, S, grad, inv_scale));
+            SBTV_TRY(gradient_from_S());
         }
         if (!replayed) {
             SBTV_TRY(upload_lam_sigma(theta));                                                    // theta(ii-1), sigma(ii-1)

@@ -196,6 +196,15 @@ __device__ __forceinline__ double2 philox_normal_pair(size_t q, unsigned step, u
     sincospi(2.0 * u2, &s, &c);
     return make_double2(r * c, r * s);
 }
+// one element of the MYULA step  X = | X + gam (prox - X)/lamb - gam grad/sigma2 + sqrt(2 gam) Z |
+// (SAPG_algorithm_Guassian.m:80-81,161), grad = scale * v; ONE definition for the element-wise kernel (scale = 1) and for
+// the epilogue of the inverse column pass, no contraction anywhere in it
+__device__ __forceinline__ double myula_nocontract(double x, double p, double v, double scale, double z, double gam,
+                                                   double lamb, double s2, double sq2g) {
+#pragma clang fp contract(off)
+    const double g = v * scale;
+    return fabs(((x + gam * (p - x) / lamb) - gam * (g / s2)) + sq2g * z);
+}
 // where the in-kernel generator of the MYULA step takes its counters from
 struct RngArgs {
     unsigned long long seed;
@@ -335,7 +344,20 @@ struct ColsPost {
     // gradient-step mode (fft_cols_inv_step): ystep <- ystep - alpha * x, x itself is not stored
     double *ystep = nullptr;
     double alpha = 0.0;
+    // MYULA mode (fft_cols_inv_myula): the transform's output is the gradient AT(AX - y); the chain state X = ystep is
+    // advanced in place (SAPG_algorithm_Guassian.m:80-81,161), the gradient is not stored
+    const double *mprox = nullptr, *msig2 = nullptr, *mZ = nullptr;
+    double mgam = 0.0, mlamb = 0.0, msq2g = 0.0;
+    RngArgs mrng = {0ull, 0u, 0u, nullptr};
+    ProxArm marm = {nullptr, nullptr, 0, 0.0, 0.0, nullptr};
 };
+// X <- | X + gam (prox - X)/lamb - gam (scale colIFFT(S))/sigma2 + sqrt(2 gam) Z |  with the gradient still in the
+// registers of the inverse column pass (same bits as fft_cols_inv followed by myula_step); Z: injected noise or null
+// (then the Philox generator, `rng`); `arm` re-arms the control blocks of the cold prox that follows, as myula_step
+// does.  Sizes of the wave-granular column pass only (fft_cols_inv_step_ok).
+int fft_cols_inv_myula(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double scale, double *X, const double *prox,
+                       const double *Z, const double *sigma2_dev, double gam, double lamb, const RngArgs *rng,
+                       const ProxArm *arm);
 int fft_cols_blocks(const FftPlan &pl);
 // y <- y - alpha * (scale * colIFFT(S)) with the transform's output still in registers (my_fista.m:25: the gradient is
 // never written); only for the sizes of the wave-granular column pass (fft_cols_inv_step_ok), same bits as
