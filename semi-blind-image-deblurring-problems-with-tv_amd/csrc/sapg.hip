@@ -599,15 +599,15 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
                 // (optimistic prox launches do not consult the control blocks: armed once before the loop)
                 SBTV_TRY(fft_cols_inv_step(ctx, fp, S, y, inv_scale, 1.0 / L, frozen_d));
             } else {
-            SBTV_TRY(fft_cols_inv_f(ctx, fp, S, grad, inv_scale, frozen_d));
-            // the gradient-step kernel also re-arms the control blocks of the cold-start prox that follows
-            const ProxArm arm{pp.ctrl, lam_d, prox_iters, 1e-3, 0.249, frozen_d};
-            if (batch <= 256) {
-                SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt, &arm, batch));
-            } else {
-                SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt));
-                SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
-            }
+                SBTV_TRY(fft_cols_inv_f(ctx, fp, S, grad, inv_scale, frozen_d));
+                // the gradient-step kernel also re-arms the control blocks of the cold-start prox that follows
+                const ProxArm arm{pp.ctrl, lam_d, prox_iters, 1e-3, 0.249, frozen_d};
+                if (batch <= 256) {
+                    SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt, &arm, batch));
+                } else {
+                    SBTV_TRY(axpy(ctx, y, grad, 1.0 / L, cnt));
+                    SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, prox_iters, 1e-3, 0.249, false, frozen_d));
+                }
             }
         }
         // x = Psi(y, tau/L): cold-start Chambolle                        (:26 ; run_moffat_demo.m:181-182)
