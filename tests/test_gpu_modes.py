@@ -116,3 +116,64 @@ def test_graph_replay_is_bit_identical_to_eager_launches(tmp_path):
         for key in outs["eager"].files:
             np.testing.assert_array_equal(outs[name][key], outs["eager"][key], err_msg=f"{name}:{key}")
     assert len(outs["eager"]["salsa_obj1"]) > 10 and outs["eager"]["moffat_alphas"][-1] != outs["eager"]["moffat_alphas"][0]
+
+
+LOOP_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "semi-blind-image-deblurring-problems-with-tv_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import sbtv
+from conftest import synth_image
+M = N = 1024                                   # a size of the wave-granular column pass (fused epilogues)
+x = synth_image(M, N, 5)
+res = {}
+st = sbtv.demo_setup("moffat", x, np.random.default_rng(1).standard_normal(x.shape), evMax=1.0)
+A = sbtv.BlurOperator(sbtv.psf_family("moffat", 7, (0.4, 3.5))[0])
+xf, obj, times, mses = sbtv.my_fista(st["y"], A, A.T, 0.03 * st["sigma"] ** 2, 1.0, sbtv.TVnorm, sbtv.Psi_TV(25), 1, 0.0, 5, x)
+res["fista_x"], res["fista_obj"], res["fista_mse"] = xf, obj, mses
+st = sbtv.demo_setup("gaussian", x, np.random.default_rng(2).standard_normal(x.shape), evMax=1.0)
+A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+out = sbtv.SALSA_v2(st["y"], A, 0.03 * st["sigma"] ** 2, "MU", 0.003, "AT", A.T, "LS", A.LS(0.003), "True_x", x,
+                    "ToleranceA", -1.0, "MAXITERA", 6, "TVINITIALIZATION", 1, "TViters", 10)
+res["salsa_x"], res["salsa_obj"] = out[0], out[3]
+for fixed in (1, 0):
+    op = dict(samples=6, warmup=3, burnIn=2, psf_size=7, phi=0.0, gamma=st["gamma"], th_init=0.01, min_th=1e-3, max_th=1.0,
+              sigma=st["sigma"], sigma_init=st["sigma_init"], sigma_min=st["sigma_min"], sigma_max=st["sigma_max"], d_scale=1.0,
+              d_exp=0.8, fix_sigma=0, seed=7, w1=0.4, w2=0.3, w1_init=0.5, w2_init=0.3, min_w1=0.1, min_w2=0.1, max_w1=1.0,
+              max_w2=1.0, fix_w1=fixed, fix_w2=fixed)
+    op["lambda"] = st["lambda"]
+    c = dict(theta=0.01, w1=10.0, w2=10.0, sigma=1000.0, lam=1.0, gam=1.0)
+    r = sbtv.SAPG_algorithm_Guassian(st["y"], op, c)[-1]
+    r = r[0] if isinstance(r, list) else r
+    for key in ("thetas", "sigmas", "logPiTraceX", "gXTrace", "Xlast_sample", "w1s"):
+        res["sapg%%d_%%s" %% (fixed, key)] = np.asarray(r[key])
+np.savez(sys.argv[1], **res)
+"""
+
+
+def test_loop_hooks_agree_with_the_default_loops(tmp_path):
+    """The launch-saving forms of the solver loops against their plain forms, each selected by its environment hook in a
+    child process: host one iteration late / synchronised (FISTA), gradient step and MYULA step as epilogues of the inverse
+    column pass / as element-wise kernels, stop rule of the SAPG prox deferred / right after the launches, optimistic /
+    exact prox launches, riding / stand-alone collector.  Same bits, except the fused MYULA epilogue (<= 2 ulp of X)."""
+    def run(name, env):
+        out = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", LOOP_CHILD % {"root": ROOT}, out], check=True, env=e, timeout=600)
+        return np.load(out)
+    ref = run("default", {})
+    exact = {"fista_lag0": {"SBTV_FISTA_LAG": "0"}, "fista_two_pass": {"SBTV_FISTA_FUSED_STEP": "0"},
+             "sapg_rule_kernel": {"SBTV_SAPG_DEFER": "0"}, "exact_prox": {"SBTV_PROX_SPEC": "0"},
+             "own_collector": {"SBTV_COLLECT_RIDE": "0"}}
+    for name, env in exact.items():
+        got = run(name, env)
+        for key in ref.files:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=name + " " + key)
+    got = run("myula_two_pass", {"SBTV_SAPG_FUSED_MYULA": "0"})
+    for key in ref.files:
+        if key.startswith("sapg"):
+            np.testing.assert_allclose(got[key], ref[key], rtol=1e-11, atol=1e-11, err_msg=key)
+        else:
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
