@@ -352,6 +352,25 @@ __device__ __forceinline__ void fused_inline_ctrl(ProxCtrl *__restrict__ c, cons
     }
 }
 
+#ifdef SBTV_FUSED_TIMELINE
+// Debug build only (make timeline -> lib/libsbtv_timeline.so; tools/chambolle_timeline.py): thread 0 of every workgroup
+// of the two-rows-per-lane kernel leaves the constant-rate clock (100 MHz) at entry, after its region has arrived, after
+// its last iteration and after its stores were issued, plus where it ran; the LAST launch's records are read back with
+// sbtv_debug_timeline().
+__device__ unsigned long long g_fused_tl[8 * 8192];
+__device__ __forceinline__ void fused_tl(int slot) {
+    if (threadIdx.x != 0 || blockIdx.x >= 8192) return;
+    unsigned long long *r = g_fused_tl + (size_t)blockIdx.x * 8;
+    r[slot] = wall_clock64();
+    if (slot == 0) {
+        r[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave / simd / cu / sh / se
+        r[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+    }
+}
+#define SBTV_TL(slot) fused_tl(slot)
+#else
+#define SBTV_TL(slot)
+#endif
 #include "tv_fused.inc"
 #include "tv_fused1.inc"
 #include "tv_pipe.inc"
@@ -1065,3 +1084,12 @@ int sbtv_TVnorm(sbtv_ctx *ctx, const double *x, int M, int N, int batch, double 
 }
 
 }  // extern "C"
+
+#ifdef SBTV_FUSED_TIMELINE
+extern "C" int sbtv_debug_timeline(sbtv_ctx *ctx, unsigned long long *out, int nrec) {
+    if (!ctx || !out || nrec < 1 || nrec > 8192) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SBTV_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(sbtv::g_fused_tl), sizeof(unsigned long long) * 8 * (size_t)nrec));
+    return 0;
+}
+#endif

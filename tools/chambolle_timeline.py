@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Phase timeline of the fused Chambolle kernel inside the SALSA loop (2048 x 2048), from the debug build
+`make -C .../csrc timeline` (lib/libsbtv_timeline.so: thread 0 of every workgroup records the 100 MHz clock at entry, after
+its region has arrived, after its last iteration and after its stores were issued, and the CU it ran on).
+Reads the records of the LAST launch of a solve (the f-writing second launch of the last outer iteration) and prints a
+markdown summary: how a workgroup's life divides into load / iterate / store, and how the two workgroups resident on a
+CU overlap those phases.        python3 tools/chambolle_timeline.py > profiles/<tag>_chambolle_timeline.md"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd")
+os.environ.setdefault("SBTV_LIBRARY", os.path.join(PKG, "lib", "libsbtv_timeline.so"))
+sys.path.insert(0, ROOT); sys.path.insert(0, PKG)
+import numpy as np, torch, sbtv, bench
+
+ctx = sbtv.default_context(0)
+x, y, sigma, noise = bench.make_problem(1, 2048)
+yd, xd = sbtv.to_device(y), sbtv.to_device(x)
+A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, *bench.W_TRUE), ctx=ctx)
+mu, tau = bench.THETA / 10, bench.THETA * sigma ** 2
+def solve(k):
+    return sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0, "MAXITERA", k,
+                         "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+solve(300)
+solve(40); torch.cuda.synchronize()
+ntile = int(os.environ.get("NREC", 18 * 98))
+rec = np.zeros((ntile, 8), dtype=np.uint64)
+ctx.lib.sbtv_debug_timeline.restype = C.c_int
+ctx.lib.sbtv_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+rc = ctx.lib.sbtv_debug_timeline(ctx.h, rec.ctypes.data_as(C.c_void_p), ntile)
+assert rc == 0, rc
+t = rec[:, :4].astype(np.int64)
+t -= t[:, 0].min()
+us = t / 100.0                                           # 100 MHz ticks -> microseconds
+load, comp, store = us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2]
+life = us[:, 3] - us[:, 0]
+span = us[:, 3].max()
+hw, xcc = rec[:, 4].astype(np.int64), rec[:, 5].astype(np.int64) & 0xF
+cu_key = (xcc << 8) | (((hw >> 13) & 0x7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)
+keys = np.unique(cu_key)
+def q(a): return "%.1f / %.1f / %.1f" % (np.percentile(a, 10), np.median(a), np.percentile(a, 90))
+print("# Fused Chambolle kernel: where a workgroup's time goes (2048², in the SALSA loop, one launch of 1 764 workgroups)\n")
+print("`tools/chambolle_timeline.py` on the debug build (`make timeline`): thread 0 of every workgroup stamps the 100 MHz clock at")
+print("entry, when its region (g, px, py) has arrived, after its 5 iterations, and when its stores are issued.  Last launch of a")
+print("40-iteration solve (the second, f-writing launch of an outer iteration).\n")
+print("| quantity | value |\n|---|---|")
+print(f"| launch, first entry to last exit | {span:.1f} µs |")
+print(f"| CUs seen / workgroups per CU | {len(keys)} / {ntile / len(keys):.2f} |")
+print(f"| workgroup life (10 % / median / 90 %) | {q(life)} µs |")
+print(f"| … waiting for its region | {q(load)} µs ({100 * load.sum() / life.sum():.0f} % of all workgroup time) |")
+print(f"| … 5 iterations | {q(comp)} µs ({100 * comp.sum() / life.sum():.0f} %) |")
+print(f"| … issuing its stores (f, px, py) | {q(store)} µs ({100 * store.sum() / life.sum():.0f} %) |")
+# per CU: time with 0 / 1 / 2 workgroups in their iteration phase
+grid = np.arange(0.0, span, 0.05)
+busy = np.zeros((3,))
+resident = np.zeros((3,))
+for k in keys:
+    m = cu_key == k
+    c = np.zeros_like(grid); r = np.zeros_like(grid)
+    for a, b_, lo, hi in zip(us[m, 1], us[m, 2], us[m, 0], us[m, 3]):
+        c += (grid >= a) & (grid < b_)
+        r += (grid >= lo) & (grid < hi)
+    for n in range(3):
+        busy[n] += np.mean(np.minimum(c, 2) == n)
+        resident[n] += np.mean(np.minimum(r, 2) == n)
+busy /= len(keys); resident /= len(keys)
+print(f"| share of the launch a CU has 2 / 1 / 0 workgroups resident | {100 * resident[2]:.0f} % / {100 * resident[1]:.0f} % / {100 * resident[0]:.0f} % |")
+print(f"| share of the launch a CU has 2 / 1 / 0 workgroups ITERATING | {100 * busy[2]:.0f} % / {100 * busy[1]:.0f} % / {100 * busy[0]:.0f} % |")
+starts = np.sort(us[:, 0])
+print(f"| entry times: first 512 workgroups within | {starts[511]:.1f} µs; the last workgroup enters at {starts[-1]:.1f} µs |")
+print(f"| time after the last workgroup ENTERED (tail) | {span - starts[-1]:.1f} µs |")
