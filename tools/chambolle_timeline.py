@@ -68,3 +68,11 @@ print(f"| share of the launch a CU has 2 / 1 / 0 workgroups ITERATING | {100 * b
 starts = np.sort(us[:, 0])
 print(f"| entry times: first 512 workgroups within | {starts[511]:.1f} µs; the last workgroup enters at {starts[-1]:.1f} µs |")
 print(f"| time after the last workgroup ENTERED (tail) | {span - starts[-1]:.1f} µs |")
+# is the XCD of a workgroup what the tile order assumes (workgroup id mod 8)?
+ids = np.arange(ntile)
+same = np.mean(xcc == (ids & 7))
+print(f"| workgroups whose XCC_ID equals (workgroup id mod 8) | {100 * same:.1f} % |")
+for off in range(8):
+    m = np.mean(xcc == ((ids + off) & 7))
+    if m > 0.5 and off: print(f"| … equals (workgroup id + {off}) mod 8 | {100 * m:.1f} % |")
+print(f"| distinct XCC_IDs seen | {len(np.unique(xcc))} |")
