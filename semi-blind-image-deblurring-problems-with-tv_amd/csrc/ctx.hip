@@ -428,6 +428,51 @@ int sbtv_last_timing(const sbtv_ctx *ctx, double out[4]) {
     return 0;
 }
 
+int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[9]) {
+    if (!ctx || !out) return SBTV_ERR_BADARG;
+    const HostStats &h = ctx->hstat;
+    const double v[9] = {h.waits, h.ready_at_once, h.waits_slept, h.sleeps, h.stream_queries,
+                         h.wait_s, h.wait_max_s, h.enqueue_s, h.enqueue_max_s};
+    for (int i = 0; i < 9; ++i) out[i] = v[i];
+    return 0;
+}
+
+int sbtv_diag_workspace(sbtv_ctx *ctx, const char *name, void **dptr, size_t *bytes) {
+    if (!ctx || !name || !dptr) return SBTV_ERR_BADARG;
+    auto it = ctx->ws.find(name);
+    if (it == ctx->ws.end() || !it->second.p) return fail(ctx, SBTV_ERR_BADARG, std::string("no workspace named '") + name + "'");
+    *dptr = it->second.p;
+    if (bytes) *bytes = it->second.bytes;
+    return 0;
+}
+
+// Every SBTV_* environment switch the library reads (each is read ONCE per process, at first use).  A stray variable
+// silently changes which kernels run, so hosts that measure (bench.py) print this next to their numbers.
+int sbtv_diag_switches(char *buf, size_t cap) {
+    static const char *const names[] = {
+        "SBTV_CANARY", "SBTV_COLLECT_RIDE", "SBTV_EXACT", "SBTV_FFT_WAVE", "SBTV_FISTA_FUSED_STEP", "SBTV_FISTA_LAG",
+        "SBTV_FUSED_VARIANT", "SBTV_GRAPH", "SBTV_INLINE_CTRL", "SBTV_PROX_PIPE", "SBTV_PROX_SPEC", "SBTV_ROWS_KERNEL",
+        "SBTV_ROWS_PIPE", "SBTV_ROWS_RK", "SBTV_ROWS_V", "SBTV_SAPG_DEFER", "SBTV_SAPG_FUSED_MYULA", "SBTV_SAPG_HOST",
+        "SBTV_SINGLE_STEP", "SBTV_SPIN", "SBTV_TAG_SPIN_US", "SBTV_U_TILED"};
+    if (!buf || cap == 0) return SBTV_ERR_BADARG;
+    std::string s;
+    int nset = 0;
+    for (const char *n : names)
+        if (const char *e = getenv(n)) {
+            s += (nset++ ? " " : "");
+            s += n;
+            s += "=";
+            s += e;
+        }
+#ifdef SBTV_LAB
+    s += (nset ? " " : "");
+    s += "[build: SBTV_LAB]";
+#endif
+    if (s.size() + 1 > cap) s.resize(cap - 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return nset;
+}
+
 int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad) {
     if (!ctx) return SBTV_ERR_BADARG;
     SBTV_HIP(ctx, hipSetDevice(ctx->device));

@@ -1438,7 +1438,9 @@ int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int re
     SBTV_TRY(psf_spectrum(ctx, pl, taps_d, 7, D1));
     SBTV_TRY(psf_spectrum(ctx, pl, taps_d, 7, D2));
     ProxPlan pp;
-    if (pass == 7 || pass == 8) SBTV_TRY(prox_plan(ctx, M, N, batch, &pp, "diag.prox"));
+    const bool pass_steps = (pass >= 11 && pass <= 15);      // one optimistic fused launch of pass - 10 Chambolle steps
+    if (pass == 7 || pass == 8 || pass_steps) SBTV_TRY(prox_plan(ctx, M, N, batch, &pp, "diag.prox"));
+    int launch_no = 0;
     const double inv_scale = 1.0 / ((double)pl.n1 * N);
     const double specb = 16.0 * (double)(pl.n1 + 1) * N * batch, img = 8.0 * (double)cnt;
     double bytes = 0.0;
@@ -1471,10 +1473,19 @@ int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int re
                 bytes = (40.0 * 25 + 8.0) * (double)cnt;
                 SBTV_TRY(prox_reset(ctx, pp, lam_d, 1.0, 25, 1e-3, 0.249, false, nullptr));
                 return prox_iterate(ctx, pp, g, 25, x, true);
-            default: return fail(ctx, SBTV_ERR_BADARG, "sbtv_diag_time_pass: unknown pass");
+            default:
+                if (pass_steps) {
+                    // ONE fused launch of K warm-started steps without f and without control kernels (the first launch of
+                    // a SALSA prox): t(K) = fixed (region load / store, fill and drain of the grid) + K x per-step
+                    const int K = pass - 10;
+                    if (!prox_spec_ok(pp, g, nullptr, K)) return fail(ctx, SBTV_ERR_BADARG, "sbtv_diag_time_pass: no fused launch for this shape");
+                    bytes = 40.0 * (double)cnt;
+                    return prox_iterate(ctx, pp, g, K, nullptr, false, 1, (launch_no++) & 1, nullptr);
+                }
+                return fail(ctx, SBTV_ERR_BADARG, "sbtv_diag_time_pass: unknown pass");
         }
     };
-    if (pass == 7) {
+    if (pass == 7 || pass_steps) {
         // warm start: zero duals in slot 0 and a control block that SELECTS slot 0 (a fresh control buffer holds
         // garbage, and `keep_cur` below would then index the dual buffer with it)
         SBTV_TRY(prox_zero_duals(ctx, pp));

@@ -443,34 +443,58 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // host is normally one iteration ahead), yielding the core between polls.  No HIP call in the normal case: a
     // stream query makes the runtime append a marker packet, which costs the stream 5-6 us before the next kernel.
     // Only after 50 ms without the tags is the stream asked, so that a failed launch cannot leave the host waiting.
-    static const bool tag_spin_only = getenv("SBTV_TAG_SPIN") != nullptr;     // experiment: never sleep between polls
+    // The wait has three phases: (1) spin on the tags for up to `spin_us` microseconds (default 150; SBTV_TAG_SPIN_US):
+    // an outer iteration of a small image takes 50 us and only ONE more iteration is queued behind it, while a
+    // nanosleep of 5 us returns after 55-60 us (the kernel's default timer slack is 50 us) or much later when the core
+    // went into a deep idle state - a host that sleeps there lets the queue run dry and a 512^2 solve then runs at a
+    // third of its speed (the "slow mode" of round 2, `sbtv_last_host_stats`); (2) sleep between polls - a 2048^2
+    // iteration takes 240 us, the spin would burn a core for nothing; (3) after 50 ms ask the stream.
+    static const double spin_us = [] {
+        const char *e = getenv("SBTV_TAG_SPIN_US");
+        return e ? atof(e) : 150.0;
+    }();
+    ctx->hstat = HostStats{};
     auto wait_tags = [&](int slot, int outer) -> int {
         volatile const double *tg = tags_h + (size_t)slot * batch * SALSA_TAGS;
         const double want = (double)outer;
         const int ntag = 8 + (slot_spec[slot] ? opts->TViters : 0);
-        auto t_begin = std::chrono::steady_clock::now();
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto t_query = t_begin;
+        bool slept = false;
+        HostStats &hs = ctx->hstat;
+        hs.waits += 1;
         for (unsigned spin = 0;; ++spin) {
             bool ready = true;
             for (int b = 0; b < batch && ready; ++b)
                 for (int i = 0; i < ntag && ready; ++i) ready = (tg[(size_t)b * SALSA_TAGS + i] == want);
-            if (ready) break;
-            if (spin < 200 || tag_spin_only) {
-                __builtin_ia32_pause();
-                if (spin < 200 || (spin & 0xfffff) != 0) continue;     // (pure spinning still asks the stream now and then)
+            if (ready) {
+                if (spin == 0) hs.ready_at_once += 1;
+                break;
             }
+            __builtin_ia32_pause();
+            if ((spin & 15) != 15) continue;                       // look at the clock every 16th poll only
+            const auto now = std::chrono::steady_clock::now();
+            if (std::chrono::duration<double, std::micro>(now - t_begin).count() < spin_us) continue;
             struct timespec ts = {0, 5000};
             nanosleep(&ts, nullptr);
-            if ((spin & 255) == 0 && std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(50)) {
+            hs.sleeps += 1;
+            slept = true;
+            if (now - t_query > std::chrono::milliseconds(50)) {
+                hs.stream_queries += 1;
                 const hipError_t e = hipStreamQuery(ctx->stream);
                 if (e == hipSuccess) {
                     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));     // everything has run: the scalars are there
                     break;
                 }
                 if (e != hipErrorNotReady) return fail_hip(ctx, e, "hipStreamQuery", __FILE__, __LINE__);
-                t_begin = std::chrono::steady_clock::now();
+                t_query = std::chrono::steady_clock::now();
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        hs.wait_s += w;
+        if (w > hs.wait_max_s) hs.wait_max_s = w;
+        if (slept) hs.waits_slept += 1;
         return 0;
     };
     // host side of outer iteration `outer`: traces + stopping rule (:444-482)
@@ -548,7 +572,13 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     int rc = 0, enq = 0, done = 0;
     while (active > 0 && done < maxiter) {
         // keep up to 1 + lag iterations in flight
-        while (rc == 0 && enq < maxiter && enq - done <= lag && active > 0) rc = enqueue(++enq);
+        while (rc == 0 && enq < maxiter && enq - done <= lag && active > 0) {
+            const auto te = std::chrono::steady_clock::now();
+            rc = enqueue(++enq);
+            const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+            ctx->hstat.enqueue_s += d;
+            if (d > ctx->hstat.enqueue_max_s) ctx->hstat.enqueue_max_s = d;
+        }
         if (rc != 0) break;
         rc = process(++done);
         if (rc != 0 || fired_early) break;

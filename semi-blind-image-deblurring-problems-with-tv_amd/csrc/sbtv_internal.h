@@ -91,6 +91,17 @@ struct SalsaScal {
     double pad;
 };
 
+// How the host side of the most recent solver loop waited for the device (sbtv_last_host_stats)
+struct HostStats {
+    double waits = 0;           // waits for the scalars of an iteration
+    double ready_at_once = 0;   // ... that found them at the first look
+    double waits_slept = 0;     // ... that went past the spin window and slept at least once
+    double sleeps = 0;          // nanosleep calls
+    double stream_queries = 0;  // the 50 ms fallback: the stream was asked
+    double wait_s = 0, wait_max_s = 0;         // host time inside the waits: total, longest
+    double enqueue_s = 0, enqueue_max_s = 0;   // host time spent enqueueing iterations: total, longest
+};
+
 struct DevBuf {
     void *p = nullptr;       // what the kernels see
     void *base = nullptr;    // what hipMalloc returned (p - guard band in canary mode, else p)
@@ -106,6 +117,7 @@ struct sbtv_ctx {
     std::string err;
     long long calls = 0;
     double timing[4] = {0, 0, 0, 0};
+    sbtv::HostStats hstat;
     std::map<std::string, sbtv::DevBuf> ws;   // named device workspaces (grow-only)
     std::map<int, double2 *> twiddles;         // n -> exp(-2 pi i k / n), k < n
     std::map<int, double2 *> any_axes;         // n -> Bluestein tables of the arbitrary-size path (fft_any.inc)

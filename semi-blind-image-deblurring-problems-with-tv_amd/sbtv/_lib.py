@@ -108,6 +108,9 @@ SIGNATURES = {
     "sbtv_MSE": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
+    "sbtv_last_host_stats": (_I, [_P, C.POINTER(_D)]),
+    "sbtv_diag_workspace": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "sbtv_diag_switches": (_I, [C.c_char_p, C.c_size_t]),
     "sbtv_diag_time_pass": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
 }
 
@@ -195,7 +198,8 @@ class Context:
         return dict(enabled=bool(en.value), buffers=nb.value, bad_bytes=bad.value)
 
     PASSES = {"cols_fwd": 0, "rows_salsa": 1, "cols_inv_post": 2, "cols_inv": 3, "rows_fwd": 4, "rows_grad": 5,
-              "rows_gradf": 6, "prox10_warm": 7, "prox25_cold": 8}
+              "rows_gradf": 6, "prox10_warm": 7, "prox25_cold": 8,
+              "fused_steps1": 11, "fused_steps2": 12, "fused_steps3": 13, "fused_steps4": 14, "fused_steps5": 15}
 
     def time_pass(self, name, M, N, batch=1, reps=20):
         """Average ms per launch and algorithmic bytes of one pass of the hot path (sbtv_diag_time_pass)."""
@@ -215,6 +219,37 @@ class Context:
         out = (C.c_double * 4)()
         self.check(self.lib.sbtv_last_timing(self.h, out))
         return dict(loop_ms=out[0], chambolle_ms=out[1], chambolle_launches=out[2], chambolle_bytes=out[3])
+
+
+    HOST_STATS = ("waits", "ready_at_once", "waits_slept", "sleeps", "stream_queries", "wait_s", "wait_max_s",
+                  "enqueue_s", "enqueue_max_s")
+
+    def last_host_stats(self):
+        """How the host side of the last SALSA_v2 call waited for the device (sbtv_last_host_stats)."""
+        out = (C.c_double * 9)()
+        self.check(self.lib.sbtv_last_host_stats(self.h, out))
+        return dict(zip(self.HOST_STATS, out))
+
+    def workspace(self, name, M, N, batch=1):
+        """Host copy of an internal workspace that holds `batch` column-major M x N images (sbtv_diag_workspace),
+        e.g. "salsa.u" / "salsa.bu" after a SALSA_v2 call -> (batch, M, N) array (or (M, N))."""
+        p, nb = _P(), C.c_size_t(0)
+        self.check(self.lib.sbtv_diag_workspace(self.h, name.encode(), C.byref(p), C.byref(nb)))
+        need = 8 * M * N * batch
+        if nb.value < need:
+            raise ValueError(f"workspace {name} holds {nb.value} bytes, {need} wanted")
+        buf = np.empty((batch, N, M), dtype=np.float64)
+        self.sync()
+        self.check(self.lib.sbtv_memcpy_d2h(self.h, vptr(buf), p, need))
+        a = np.transpose(buf, (0, 2, 1))
+        return a[0] if batch == 1 else a
+
+
+def switches():
+    """The SBTV_* environment switches set in this process ("" = default kernels); sbtv_diag_switches."""
+    buf = C.create_string_buffer(2048)
+    load_library().sbtv_diag_switches(buf, 2048)
+    return buf.value.decode()
 
 
 _default_ctx = {}

@@ -76,3 +76,15 @@ for off in range(8):
     m = np.mean(xcc == ((ids + off) & 7))
     if m > 0.5 and off: print(f"| … equals (workgroup id + {off}) mod 8 | {100 * m:.1f} % |")
 print(f"| distinct XCC_IDs seen | {len(np.unique(xcc))} |")
+
+# machine-readable summary for bench.py's roofline block (tail_frac), stamped with the kernel sources it was measured on
+if os.environ.get("TIMELINE_JSON"):
+    import json
+    json.dump({"source_sha256": bench.source_sha(), "image": [2048, 2048], "workgroups": int(ntile),
+               "launch_us": float(span), "tail_us": float(span - starts[-1]), "last_entry_us": float(starts[-1]),
+               "workgroup_life_us_median": float(np.median(life)), "load_wait_us_median": float(np.median(load)),
+               "iterate_us_median": float(np.median(comp)), "store_issue_us_median": float(np.median(store)),
+               "cu_two_workgroups_iterating_frac": float(busy[2]), "cu_no_workgroup_iterating_frac": float(busy[0]),
+               "how": "tools/chambolle_timeline.py on `make timeline` (clock stamps by thread 0 of every workgroup), last "
+                      "launch of a 40-iteration SALSA solve at 2048^2"},
+              open(os.environ["TIMELINE_JSON"], "w"), indent=1)
