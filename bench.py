@@ -38,6 +38,16 @@ Prints ONE JSON line (rank 0).  Besides the contract keys:
   pre_roll_steps  every untimed iteration that ran before the timed region (converged solve, clock ramp-up, --warmup)
   cpu_baseline  the NumPy oracle on the host cores (N = 1 only), final_psnr_db, batched, switches (SBTV_* variables set)
 """
+import os as _os
+# Host-side thread pools must not spin while the GPU is being timed: NumPy's OpenBLAS starts up to 64 threads for one
+# `np.linalg.norm` of the problem set-up and each of them busy-waits for ~100 ms afterwards; on a box whose container has
+# a CPU quota (16 cores here, cgroup cpu.max) that uses up the quota of the next 100 ms periods and the kernel then holds
+# EVERY thread of the container - including the one that feeds the GPU - until the period ends.  That was the "slow
+# mode" of the 512 x 512 samples in round 2 (profiles/r03_slow_mode_512.md).  Set before NumPy / torch are imported.
+_os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+_os.environ.setdefault("MKL_NUM_THREADS", "1")
+_os.environ.setdefault("OMP_NUM_THREADS", "1")
+
 import argparse
 import glob
 import hashlib
@@ -276,6 +286,48 @@ def fixture_check(tag, psnr_db, n_outer):
     return {"matches": bool(abs(psnr_db - want_psnr) <= 1e-3 and n_outer == want_n), "fixture_psnr_db": want_psnr,
             "fixture_outer_iterations": want_n, "abs_dpsnr_db": abs(psnr_db - want_psnr),
             "fixture": "tests/golden/large_configs.npz:" + tag}
+
+
+def cgroup_throttled_us():
+    """Microseconds this container's threads were held back by its CPU quota so far (cgroup v2 cpu.stat), or None."""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1])
+    except OSError:
+        pass
+    return None
+
+
+def thread_cpu_ms():
+    """CPU time of every thread of this process so far: {tid: (name, ms)} (/proc/self/task/*/stat, 10 ms ticks)."""
+    out = {}
+    tick = 1000.0 / os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open(f"/proc/self/task/{tid}/stat").read()
+            except OSError:
+                continue
+            f = st[st.rindex(")") + 2:].split()
+            out[int(tid)] = (st[st.index("(") + 1:st.rindex(")")], (int(f[11]) + int(f[12])) * tick)
+    except OSError:
+        pass
+    return out
+
+
+def thread_cpu_delta(a, b, top=6):
+    """Who used the CPU between two thread_cpu_ms() snapshots: thread count, total ms, the `top` consumers by name."""
+    d = {}
+    for tid, (nm, ms) in b.items():
+        used = ms - a.get(tid, (nm, 0.0))[1]
+        if used > 0:
+            d[nm] = d.get(nm, [0, 0.0])
+            d[nm][0] += 1
+            d[nm][1] += used
+    items = sorted(d.items(), key=lambda kv: -kv[1][1])[:top]
+    return {"threads_alive": len(b), "cpu_ms_total": sum(v[1] for v in d.values()),
+            "top": [{"name": k, "threads": v[0], "cpu_ms": v[1]} for k, v in items]}
 
 
 def median(v):
@@ -528,14 +580,22 @@ def main():
             samples5, hstats5 = [], []
             for _ in range(5):       # launch-bound regime: every sample is listed, the MEDIAN is the value
                 torch.cuda.synchronize()
+                thr0 = cgroup_throttled_us()
+                tc0 = thread_cpu_ms()
                 t5 = time.perf_counter()
                 solve(k5, -1.0, y5d, x5d, tau5)
                 torch.cuda.synchronize()
                 samples5.append(time.perf_counter() - t5)
                 hs = ctx.last_host_stats()
+                thr1 = cgroup_throttled_us()
                 hstats5.append({"waits_slept": int(hs["waits_slept"]), "sleeps": int(hs["sleeps"]),
                                 "stream_queries": int(hs["stream_queries"]), "wait_max_us": 1e6 * hs["wait_max_s"],
-                                "enqueue_max_us": 1e6 * hs["enqueue_max_s"], "device_ms": ctx.last_timing()["loop_ms"]})
+                                "wait_max_outer": int(hs["wait_max_outer"]),
+                                "enqueue_max_us": 1e6 * hs["enqueue_max_s"], "device_ms": ctx.last_timing()["loop_ms"],
+                                "thread_ctx_switches_vol_invol": [int(hs["nvcsw"]), int(hs["nivcsw"])],
+                                "thread_page_faults_minor_major": [int(hs["minflt"]), int(hs["majflt"])],
+                                "cgroup_throttled_us": None if thr1 is None or thr0 is None else thr1 - thr0,
+                                "thread_cpu": thread_cpu_delta(tc0, thread_cpu_ms())})
             e5 = median(samples5)
             tm5 = ctx.last_timing()
             # 16 independent 512x512 images in one call (the unit when many small images share a GPU): every launch

@@ -347,7 +347,9 @@ int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N,
  * sbtv_last_host_stats: how the HOST side of the most recent sbtv_SALSA_v2 call waited for the device (the loop keeps one
  *   iteration queued ahead and polls completion tags in pinned memory): out = {waits, waits that found the scalars at
  *   the first look, waits that went past the spin window and slept, nanosleep calls, stream queries (the 50 ms
- *   fallback), seconds inside the waits, longest wait, seconds spent enqueueing, longest enqueue of one iteration}.
+ *   fallback), seconds inside the waits, longest wait, seconds spent enqueueing, longest enqueue of one iteration,
+ *   the outer iteration the longest wait was for, and what the operating system did to the calling thread during the
+ *   loop (getrusage(RUSAGE_THREAD) deltas): voluntary / involuntary context switches, minor / major page faults}.
  * sbtv_diag_workspace: device address / capacity of a named internal workspace of the context, e.g. "salsa.u",
  *   "salsa.bu", "salsa.g": the state the most recent sbtv_SALSA_v2 call left behind (parity tests of intermediate arrays;
  *   with the default one-iteration lag they belong to the last iteration ENQUEUED, which is the stopping iteration
@@ -355,7 +357,7 @@ int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N,
  * sbtv_diag_switches: the SBTV_* environment switches that are set in this process, as "NAME=value ..." (returns their
  *   number; 0 and an empty string = the default kernels).  They are tuning / A-B hooks, read once per process. */
 int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad);
-int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[9]);
+int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[14]);
 int sbtv_diag_workspace(sbtv_ctx *ctx, const char *name, void **dptr, size_t *bytes);
 int sbtv_diag_switches(char *buf, size_t cap);
 int sbtv_diag_time_pass(sbtv_ctx *ctx, int pass, int M, int N, int batch, int reps, double *ms_avg, double *alg_bytes);

@@ -428,12 +428,13 @@ int sbtv_last_timing(const sbtv_ctx *ctx, double out[4]) {
     return 0;
 }
 
-int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[9]) {
+int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[14]) {
     if (!ctx || !out) return SBTV_ERR_BADARG;
     const HostStats &h = ctx->hstat;
-    const double v[9] = {h.waits, h.ready_at_once, h.waits_slept, h.sleeps, h.stream_queries,
-                         h.wait_s, h.wait_max_s, h.enqueue_s, h.enqueue_max_s};
-    for (int i = 0; i < 9; ++i) out[i] = v[i];
+    const double v[14] = {h.waits, h.ready_at_once, h.waits_slept, h.sleeps, h.stream_queries,
+                          h.wait_s, h.wait_max_s, h.enqueue_s, h.enqueue_max_s, h.wait_max_outer,
+                          h.nvcsw, h.nivcsw, h.minflt, h.majflt};
+    for (int i = 0; i < 14; ++i) out[i] = v[i];
     return 0;
 }
 

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 
+#include <sys/resource.h>
 #include <time.h>
 
 #include "sbtv_internal.h"
@@ -454,6 +455,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         return e ? atof(e) : 150.0;
     }();
     ctx->hstat = HostStats{};
+    struct rusage ru0 {};
+    (void)getrusage(RUSAGE_THREAD, &ru0);
     auto wait_tags = [&](int slot, int outer) -> int {
         volatile const double *tg = tags_h + (size_t)slot * batch * SALSA_TAGS;
         const double want = (double)outer;
@@ -493,7 +496,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         hs.wait_s += w;
-        if (w > hs.wait_max_s) hs.wait_max_s = w;
+        if (w > hs.wait_max_s) {
+            hs.wait_max_s = w;
+            hs.wait_max_outer = (double)outer;
+        }
         if (slept) hs.waits_slept += 1;
         return 0;
     };
@@ -596,6 +602,14 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                              times, mses, numA, numAt, n_outer, flags);
     }
     SBTV_TRY(read_initial());
+    {
+        struct rusage ru1 {};
+        (void)getrusage(RUSAGE_THREAD, &ru1);
+        ctx->hstat.nvcsw = (double)(ru1.ru_nvcsw - ru0.ru_nvcsw);
+        ctx->hstat.nivcsw = (double)(ru1.ru_nivcsw - ru0.ru_nivcsw);
+        ctx->hstat.minflt = (double)(ru1.ru_minflt - ru0.ru_minflt);
+        ctx->hstat.majflt = (double)(ru1.ru_majflt - ru0.ru_majflt);
+    }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (x_out) {
         // image b's result is the x written by ITS last processed iteration

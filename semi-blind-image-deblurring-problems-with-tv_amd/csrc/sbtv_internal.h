@@ -100,6 +100,10 @@ struct HostStats {
     double stream_queries = 0;  // the 50 ms fallback: the stream was asked
     double wait_s = 0, wait_max_s = 0;         // host time inside the waits: total, longest
     double enqueue_s = 0, enqueue_max_s = 0;   // host time spent enqueueing iterations: total, longest
+    double wait_max_outer = 0;  // outer iteration whose scalars the longest wait was for
+    // what the operating system did to the calling thread during the loop (getrusage(RUSAGE_THREAD) deltas): a host
+    // thread that is taken off its core, or that blocks in a page fault, lets the one-deep queue of a small image run dry
+    double nvcsw = 0, nivcsw = 0, minflt = 0, majflt = 0;
 };
 
 struct DevBuf {

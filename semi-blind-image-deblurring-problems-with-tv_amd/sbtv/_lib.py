@@ -222,11 +222,11 @@ class Context:
 
 
     HOST_STATS = ("waits", "ready_at_once", "waits_slept", "sleeps", "stream_queries", "wait_s", "wait_max_s",
-                  "enqueue_s", "enqueue_max_s")
+                  "enqueue_s", "enqueue_max_s", "wait_max_outer", "nvcsw", "nivcsw", "minflt", "majflt")
 
     def last_host_stats(self):
         """How the host side of the last SALSA_v2 call waited for the device (sbtv_last_host_stats)."""
-        out = (C.c_double * 9)()
+        out = (C.c_double * 14)()
         self.check(self.lib.sbtv_last_host_stats(self.h, out))
         return dict(zip(self.HOST_STATS, out))
 

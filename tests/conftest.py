@@ -1,6 +1,12 @@
 import os
 import sys
 
+# BLAS / OpenMP pools busy-wait after every call; with 64+ threads inside a CPU-quota container that throttles the whole
+# process, also the thread that feeds the GPU (profiles/r03_slow_mode_512.md).  The oracle's FFTs use scipy.fft's own
+# `workers` pool and are not affected.
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "OMP_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 import pytest
 
@@ -11,6 +17,13 @@ for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+try:                                      # NumPy may have been imported (by a plugin) before the variables were set
+    import threadpoolctl
+    threadpoolctl.threadpool_limits(limits=1, user_api="blas")
+except Exception:                         # pragma: no cover
+    pass
 
 
 def pytest_configure(config):

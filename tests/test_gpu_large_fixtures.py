@@ -169,21 +169,35 @@ def test_sapg_shared_chains_2048_match_fixture(ctx, fx):
         assert p[0] != p[1] != p[2] and np.all((p > 0.1) & (p < 1.0))
 
 
+def _throttled_us():
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1])
+    except OSError:
+        pass
+    return 0
+
+
 def test_salsa_512_host_wait_takes_no_fallback(ctx):
     """The host side of the SALSA loop polls completion tags in pinned memory; its 50 ms fallback (ask the stream) must
-    never fire in a healthy run, and a 400-step solve of a 512^2 image (54 us per iteration) must not starve the GPU:
-    the device-side duration of the call stays within 1.5x of the best of three."""
+    never fire in a healthy run, and a 400-step solve of a 512^2 image (50 us per iteration, ONE iteration queued ahead)
+    must not starve the GPU: the device-side duration of the call stays within 1.5x of the best one - unless the
+    operating system held the host thread back (a CPU-quota throttle of the container, the cause of round 2's "slow
+    mode", profiles/r03_slow_mode_512.md), which the library cannot prevent and cpu.stat reveals."""
     import sbtv
     pr = lc.salsa512()
     A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, *pr["w"]), ctx=ctx)
     yd, xd = sbtv.to_device(pr["y"]), sbtv.to_device(pr["x"])
-    dev_ms = []
-    for rep in range(4):
+    runs = []
+    for rep in range(5):
+        t0 = _throttled_us()
         sbtv.SALSA_v2(yd, A, pr["tau"], "MU", pr["mu"], "AT", A.T, "LS", A.LS(pr["mu"]), "True_x", xd, "StopCriterion", 1,
                       "ToleranceA", -1.0, "MAXITERA", 400, "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
         hs = ctx.last_host_stats()
         assert hs["stream_queries"] == 0, hs
         assert hs["waits"] == 400
-        if rep:
-            dev_ms.append(ctx.last_timing()["loop_ms"])
-    assert max(dev_ms) < 1.5 * min(dev_ms), dev_ms
+        runs.append((ctx.last_timing()["loop_ms"], _throttled_us() - t0, round(1e6 * hs["wait_max_s"])))
+    clean = [r[0] for r in runs[1:] if r[1] == 0]
+    assert len(clean) >= 2, runs
+    assert max(clean) < 1.5 * min(clean), runs

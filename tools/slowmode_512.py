@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--samples", type=int, default=12)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--heavy", action="store_true", help="first what bench.py does before its 512^2 block: a 2048^2 solve, "
+                                                         "the per-pass timings, large host arrays made and dropped")
     a = ap.parse_args()
     import torch
     import bench
@@ -39,6 +41,15 @@ def main():
     def solve(n):
         return sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "StopCriterion", 1,
                              "ToleranceA", -1.0, "MAXITERA", n, "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+    if a.heavy:
+        import numpy as np
+        xb, yb, sb, _ = bench.make_problem(seed=1, size=2048)
+        ybd, xbd = sbtv.to_device(yb, "cuda:0"), sbtv.to_device(xb, "cuda:0")
+        sbtv.SALSA_v2(ybd, A, bench.THETA * sb ** 2, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xbd, "StopCriterion", 1,
+                      "ToleranceA", -1.0, "MAXITERA", 300, "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+        bench.pass_block(ctx, 2048, ("cols_fwd", "rows_salsa", "cols_inv_post", "prox10_warm"), 50)
+        big = sbtv.to_device(np.stack([yb] * 4), "cuda:0")
+        del big, ybd, xbd, xb, yb
     solve(50)
     rows = []
     for i in range(a.samples):
@@ -46,6 +57,7 @@ def main():
         if pause:
             time.sleep(pause)           # the bench does host work (NumPy set-up, PSNR) between its GPU phases
         torch.cuda.synchronize()
+        thr0 = bench.cgroup_throttled_us()
         t0 = time.perf_counter()
         solve(a.steps)
         torch.cuda.synchronize()
@@ -56,7 +68,10 @@ def main():
                          device_ms=round(tm["loop_ms"], 2), waits_slept=int(hs["waits_slept"]), sleeps=int(hs["sleeps"]),
                          stream_queries=int(hs["stream_queries"]), ready_at_once=int(hs["ready_at_once"]),
                          wait_max_us=round(1e6 * hs["wait_max_s"]), wait_ms=round(1e3 * hs["wait_s"], 2),
-                         enqueue_ms=round(1e3 * hs["enqueue_s"], 2), enqueue_max_us=round(1e6 * hs["enqueue_max_s"])))
+                         enqueue_ms=round(1e3 * hs["enqueue_s"], 2), enqueue_max_us=round(1e6 * hs["enqueue_max_s"]),
+                         wait_max_outer=int(hs["wait_max_outer"]), ctxsw=[int(hs["nvcsw"]), int(hs["nivcsw"])],
+                         faults=[int(hs["minflt"]), int(hs["majflt"])],
+                         throttled_us=(bench.cgroup_throttled_us() or 0) - (thr0 or 0)))
     print(json.dumps({"switches": sbtv.switches(), "size": a.size, "steps": a.steps, "samples": rows}))
 
 
