@@ -28,7 +28,8 @@
  *   - return value: 0 = ok; < 0 argument errors (mirror the reference's
  *     error() sites); > 0 HIP runtime errors.  sbtv_last_error() gives text.
  *     Nothing throws across the boundary.
- *   - one context = one GPU = one host thread at a time.
+ *   - one context = one GPU = one host thread at a time; sbtv_group (below) bundles one context per GPU behind
+ *     one call for hosts that are a single process.
  */
 #ifndef SBTV_H
 #define SBTV_H
@@ -296,7 +297,11 @@ typedef struct sbtv_sapg_opts {
  *          sbtv_allreduce_dev_fn: it is called once per iteration with the DEVICE address of the same 6 doubles and
  *          the library's stream and must enqueue an in-place SUM over the processes that is ordered after the work
  *          already in that stream and before work enqueued later (e.g. ncclAllReduce / torch.distributed.all_reduce
- *          on that stream); it must not wait for the GPU.  In that mode a failing rank returns its error at once. */
+ *          on that stream); it must not wait for the GPU.  In that mode the host runs ahead of the device, so a rank whose
+ *          iteration fails locally keeps calling reduce_fn once per remaining iteration with {0, 0, 0, 0, 0 chains,
+ *          1 failed} before it returns its error; its peers latch the flag on the device and return SBTV_ERR_PEER at
+ *          their next synchronisation (every 1024 iterations and at the end).  Only a failure of reduce_fn itself makes
+ *          a rank return at once. */
 typedef int (*sbtv_allreduce_fn)(void *user, double *buf, int n);
 typedef int (*sbtv_allreduce_dev_fn)(void *user, double *dev_buf, int n, void *hip_stream);
 int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
@@ -327,6 +332,39 @@ int sbtv_max_eigenval(sbtv_ctx *ctx, const double *taps, int taille, const doubl
  * sbtv_PSNR: utils/PSNR.m:2-4 ; sbtv_MSE: utils/MSE.m:1-4 (dB). out[batch]. */
 int sbtv_PSNR(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags);
 int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N, int batch, double *out, int flags);
+
+/* ---- several GPUs behind ONE host process ---------------------------------------------
+ * The reference's host is a single MATLAB process (run_Gaussian_demo.m:199 calls the SAPG loop, :229-242 SALSA_v2);
+ * a group gives such a host all the GPUs of a node without a second process: one context and one host thread per
+ * entry of `devices` (an ordinal may repeat: "virtual shards" on one GPU).  Items are dealt to the shards in
+ * contiguous blocks (sbtv_group_shard_of); only min(n, n_items) shards take part in a call.  All pointers are HOST
+ * pointers, laid out exactly as for the single-context entry points with batch = n_items.
+ *   sbtv_SALSA_v2_sharded        independent images: no exchange; image k is computed bit for bit as by sbtv_SALSA_v2.
+ *   sbtv_SAPG_algorithm_sharded  op->share_gradients = 0: independent images / chains (chain i draws the Philox stream
+ *                                op->chain_offset + i whatever the sharding).  share_gradients = 1: n_items MYULA chains
+ *                                on ONE image y (SAPG_algorithm_moffat.m:143-173, `G = mean(g_*)`), the six gradient sums
+ *                                added up across the shards once per iteration by an in-process, in-stream exchange
+ *                                (pinned peer-visible slots + events; no GPU ever waits for its host, no RCCL).  A shard
+ *                                that fails keeps the exchange in step until the end of the loop; the others return
+ *                                SBTV_ERR_PEER and the call returns the failing shard's status (sbtv_group_last_error).
+ */
+typedef struct sbtv_group sbtv_group;
+int         sbtv_group_create(const int *devices, int n, sbtv_group **out);
+int         sbtv_group_destroy(sbtv_group *g);
+int         sbtv_group_size(const sbtv_group *g);
+sbtv_ctx   *sbtv_group_ctx(sbtv_group *g, int i);            /* context of shard i (e.g. for sbtv_last_timing) */
+const char *sbtv_group_last_error(const sbtv_group *g);
+/* which shard computes `item` of n_items, and that shard's block [first, first + count) */
+int         sbtv_group_shard_of(const sbtv_group *g, int n_items, int item, int *shard, int *first, int *count);
+int sbtv_SALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_items,
+                          const double *taps, int taille, const double *tau, const double *mu,
+                          const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                          double *x_out, double *objective, double *distance, double *times, double *mses,
+                          int *numA, int *numAt, int *n_outer);
+int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, int n_items,
+                                const sbtv_sapg_opts *op, const double *x0, const double *noise,
+                                double *thetas, double *ps, double *sigmas, double *logpi,
+                                double *logpi_wu, double *gx, double *grads, double *eb, double *x_last);
 
 /* ---- diagnostics (no counterpart in the reference; SURVEY.md §5 sanitizer / tracing rows) ----
  * sbtv_diag_canary: with SBTV_CANARY=1 in the environment when the context was created, every device workspace of

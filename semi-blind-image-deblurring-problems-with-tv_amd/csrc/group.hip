@@ -1,0 +1,320 @@
+// Several GPUs behind ONE host process (SURVEY.md section 8b `sbtv_ctx_create(devices[], n)`, section 8e).
+//
+// The reference's host is a single MATLAB process: run_Gaussian_demo.m:199 calls the SAPG loop and :229-242 SALSA_v2, and
+// its only in-process seam for more than one sample per update is the vestigial `for jj = 1:1 ... G = mean(g_*)` loop
+// (SAPG/SAPG_algorithm_moffat.m:143-173).  A group is n contexts (one per entry of `devices`; entries may repeat, which
+// gives "virtual shards" on one GPU) with one host thread each:
+//   * independent items (images of a batch, BASELINE configs[3]) are dealt to the shards in contiguous blocks and every
+//     shard runs the ordinary single-context entry point on its block - no exchange of any kind, and because a batched
+//     call computes image k bit for bit like image k alone, the sharded result equals the single-context one exactly;
+//   * MYULA chains on one image with averaged gradients (configs[4]) are dealt the same way and exchange six doubles per
+//     SAPG iteration through an IN-PROCESS all-reduce that never synchronises a GPU with its host: every shard's stream
+//     publishes its sums into a pinned, peer-visible slot (one tiny kernel), records an event, waits (hipStreamWaitEvent)
+//     for the events of the other shards and adds the slots up in fixed shard order (a second tiny kernel).  The host
+//     threads only meet at a barrier so that every event has been RECORDED before anybody waits for it; they run ahead of
+//     their GPUs like the single-context loop does.  No RCCL is involved (48 bytes per iteration).
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "sbtv_internal.h"
+
+namespace sbtv {
+
+// ---- abortable rendezvous of the shard threads ---------------------------------------------------------------
+struct Rendezvous {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0, waiting = 0;
+    unsigned long gen = 0;
+    bool aborted = false;
+    void reset(int n_) {
+        std::lock_guard<std::mutex> lk(m);
+        n = n_;
+        waiting = 0;
+        aborted = false;
+    }
+    // true: everybody arrived; false: somebody gave up (abort) - the caller must not wait for its peers any more
+    bool arrive() {
+        std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
+        const unsigned long g = gen;
+        if (++waiting == n) {
+            waiting = 0;
+            ++gen;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lk, [&] { return gen != g || aborted; });
+        return gen != g;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
+    }
+};
+
+constexpr int kRed = 8;       // doubles per slot (6 used: the all-reduce buffer of sbtv_SAPG_algorithm)
+
+__global__ void group_publish_kernel(const double *__restrict__ buf, double *__restrict__ slot, int n) {
+    if ((int)threadIdx.x < n) slot[threadIdx.x] = buf[threadIdx.x];
+    __threadfence_system();
+}
+// buf[i] = sum over the shards in shard order 0 .. nshards-1 (every shard computes the same bits)
+__global__ void group_sum_kernel(double *__restrict__ buf, const double *__restrict__ slots, int nshards, int n) {
+#pragma clang fp contract(off)
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < nshards; ++r) s += slots[(size_t)r * kRed + i];
+    buf[i] = s;
+}
+
+}  // namespace sbtv
+
+struct sbtv_group {
+    std::vector<int> devices;
+    std::vector<sbtv_ctx *> ctxs;
+    std::string err;
+    // in-process all-reduce state
+    double *slots_h = nullptr;                      // pinned [2 parities][n][kRed], portable + coherent
+    std::vector<double *> slots_d;                  // the same block as each shard's device sees it
+    std::vector<hipEvent_t> ev;                     // [2][n]
+    std::vector<long> iter;                         // collectives made by each shard in the current call
+    sbtv::Rendezvous rv;
+    int active = 0;                                 // shards that take part in the current call
+};
+
+namespace sbtv {
+
+struct ShardUser {
+    sbtv_group *g;
+    int rank;
+};
+
+// sbtv_allreduce_dev_fn of a shard: enqueue "sum dev_buf over the active shards" on `stream`, ordered after what is
+// already in it; never waits for a GPU
+static int group_allreduce(void *user, double *dev_buf, int n, void *stream_v) {
+    ShardUser *su = static_cast<ShardUser *>(user);
+    sbtv_group *g = su->g;
+    const int r = su->rank, ns = g->active;
+    hipStream_t st = static_cast<hipStream_t>(stream_v);
+    if (n > kRed) return 1;
+    if (ns == 1) return 0;
+    const int par = (int)(g->iter[r] & 1);
+    ++g->iter[r];
+    double *mine = g->slots_d[r] + ((size_t)par * g->devices.size() + r) * kRed;
+    hipLaunchKernelGGL(group_publish_kernel, dim3(1), dim3(64), 0, st, (const double *)dev_buf, mine, n);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(g->ev[(size_t)par * g->devices.size() + r], st) != hipSuccess) {
+        g->rv.abort();
+        return 1;
+    }
+    // every shard has recorded its event of this iteration (a wait for an event that was never recorded is a no-op)
+    if (!g->rv.arrive()) return 1;
+    for (int q = 0; q < ns; ++q)
+        if (q != r && hipStreamWaitEvent(st, g->ev[(size_t)par * g->devices.size() + q], 0) != hipSuccess) {
+            g->rv.abort();
+            return 1;
+        }
+    hipLaunchKernelGGL(group_sum_kernel, dim3(1), dim3(64), 0, st, dev_buf,
+                       (const double *)(g->slots_d[r] + (size_t)par * g->devices.size() * kRed), ns, n);
+    if (hipGetLastError() != hipSuccess) {
+        g->rv.abort();
+        return 1;
+    }
+    // Slot / event reuse two iterations later is safe without another rendezvous: shard q overwrites its slot of this
+    // parity only after its own sum of the NEXT iteration, which waited for every shard's publish of that iteration,
+    // which each shard enqueued behind its sum of THIS iteration; and q re-records this event only after the next
+    // rendezvous, by which time every shard has enqueued its waits of this one.
+    return 0;
+}
+
+static int gfail(sbtv_group *g, int code, const std::string &msg) {
+    if (g) g->err = msg;
+    set_global_error(msg);
+    return code;
+}
+
+// contiguous blocks: shard r of `ns` gets items [lo, hi)
+static inline void block_of(int n_items, int ns, int r, int *lo, int *hi) {
+    const int base = n_items / ns, extra = n_items % ns;
+    *lo = r * base + (r < extra ? r : extra);
+    *hi = *lo + base + (r < extra ? 1 : 0);
+}
+
+// run fn(rank) on one host thread per active shard; the first non-zero status (lowest rank) is returned with its message
+template <class F>
+static int run_shards(sbtv_group *g, int ns, F fn) {
+    std::vector<int> rc(ns, 0);
+    std::vector<std::thread> th;
+    th.reserve(ns);
+    for (int r = 0; r < ns; ++r)
+        th.emplace_back([&, r] {
+            rc[r] = (hipSetDevice(g->devices[r]) == hipSuccess) ? fn(r) : (int)hipErrorInvalidDevice;
+            if (rc[r] != 0) g->rv.abort();          // nobody may wait for this shard any more
+        });
+    for (auto &t : th) t.join();
+    // a shard that failed on its own is reported before one that only saw its peer fail
+    for (int pass = 0; pass < 2; ++pass)
+        for (int r = 0; r < ns; ++r)
+            if (rc[r] != 0 && (pass == 1 || rc[r] != SBTV_ERR_PEER)) {
+                g->err = "shard " + std::to_string(r) + " (device " + std::to_string(g->devices[r]) + "): " + g->ctxs[r]->err;
+                set_global_error(g->err);
+                return rc[r];
+            }
+    return 0;
+}
+
+}  // namespace sbtv
+
+using namespace sbtv;
+
+extern "C" {
+
+int sbtv_group_create(const int *devices, int n, sbtv_group **out) {
+    if (!out) return gfail(nullptr, SBTV_ERR_BADARG, "sbtv_group_create: out is NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return gfail(nullptr, SBTV_ERR_BADARG, "sbtv_group_create: 1 <= n <= 64 devices");
+    sbtv_group *g = new sbtv_group();
+    g->devices.assign(devices, devices + n);
+    g->ctxs.assign(n, nullptr);
+    g->slots_d.assign(n, nullptr);
+    g->ev.assign((size_t)2 * n, nullptr);
+    g->iter.assign(n, 0);
+    auto init = [&]() -> int {
+        for (int r = 0; r < n; ++r) {
+            const int rc = sbtv_ctx_create(devices[r], &g->ctxs[r]);
+            if (rc != 0) return gfail(g, rc, std::string("sbtv_group_create: ") + sbtv_last_error(nullptr));
+        }
+        if (hipSetDevice(devices[0]) != hipSuccess ||
+            hipHostMalloc((void **)&g->slots_h, sizeof(double) * 2 * n * kRed,
+                          hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+            return gfail(g, SBTV_ERR_NOMEM, "sbtv_group_create: cannot allocate the pinned exchange block");
+        memset(g->slots_h, 0, sizeof(double) * 2 * n * kRed);
+        for (int r = 0; r < n; ++r) {
+            void *dp = nullptr;
+            if (hipSetDevice(devices[r]) != hipSuccess || hipHostGetDevicePointer(&dp, g->slots_h, 0) != hipSuccess)
+                return gfail(g, SBTV_ERR_NODEVICE, "sbtv_group_create: the exchange block is not visible from every device");
+            g->slots_d[r] = static_cast<double *>(dp);
+            for (int p = 0; p < 2; ++p)
+                if (hipEventCreateWithFlags(&g->ev[(size_t)p * n + r], hipEventDisableTiming) != hipSuccess)
+                    return gfail(g, SBTV_ERR_NOMEM, "sbtv_group_create: hipEventCreate failed");
+        }
+        return 0;
+    };
+    const int rc = init();
+    if (rc != 0) {
+        const std::string msg = g->err;
+        (void)sbtv_group_destroy(g);
+        return gfail(nullptr, rc, msg);
+    }
+    *out = g;
+    return 0;
+}
+
+int sbtv_group_destroy(sbtv_group *g) {
+    if (!g) return 0;
+    for (size_t r = 0; r < g->ctxs.size(); ++r) {
+        (void)hipSetDevice(g->devices[r]);
+        if (g->ctxs[r]) (void)sbtv_ctx_destroy(g->ctxs[r]);
+        for (int p = 0; p < 2; ++p)
+            if (g->ev[(size_t)p * g->ctxs.size() + r]) (void)hipEventDestroy(g->ev[(size_t)p * g->ctxs.size() + r]);
+    }
+    if (g->slots_h) (void)hipHostFree(g->slots_h);
+    delete g;
+    return 0;
+}
+
+int sbtv_group_size(const sbtv_group *g) { return g ? (int)g->ctxs.size() : 0; }
+
+sbtv_ctx *sbtv_group_ctx(sbtv_group *g, int i) { return (g && i >= 0 && i < (int)g->ctxs.size()) ? g->ctxs[i] : nullptr; }
+
+const char *sbtv_group_last_error(const sbtv_group *g) { return g ? g->err.c_str() : sbtv_last_error(nullptr); }
+
+int sbtv_group_shard_of(const sbtv_group *g, int n_items, int item, int *shard, int *first, int *count) {
+    if (!g || n_items < 1 || item < 0 || item >= n_items) return SBTV_ERR_BADARG;
+    const int ns = std::min((int)g->ctxs.size(), n_items);
+    for (int r = 0; r < ns; ++r) {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        if (item >= lo && item < hi) {
+            if (shard) *shard = r;
+            if (first) *first = lo;
+            if (count) *count = hi - lo;
+            return 0;
+        }
+    }
+    return SBTV_ERR_BADARG;
+}
+
+int sbtv_SALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                          const double *tau, const double *mu, const sbtv_salsa_opts *opts, const double *true_x,
+                          const double *x_init, double *x_out, double *objective, double *distance, double *times,
+                          double *mses, int *numA, int *numAt, int *n_outer) {
+    if (!g) return SBTV_ERR_BADARG;
+    if (!y || !tau || !mu || !opts || n_items < 1 || M < 2 || N < 2)
+        return gfail(g, SBTV_ERR_BADARG, "SALSA_v2_sharded: missing required argument");
+    if (!taps) return gfail(g, SBTV_ERR_MISSING_AT, "The function handle for transpose of A is missing");
+    const int ns = std::min((int)g->ctxs.size(), n_items);
+    g->active = ns;
+    g->rv.reset(ns);
+    const size_t P = (size_t)M * N, t2 = (size_t)taille * taille, K = (size_t)(opts->maxiter > 0 ? opts->maxiter : 0);
+    auto off = [](auto *p, size_t o) { return p ? p + o : p; };
+    return run_shards(g, ns, [&](int r) -> int {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        const size_t b = (size_t)lo;
+        return sbtv_SALSA_v2(g->ctxs[r], y + b * P, M, N, hi - lo, taps + b * t2, taille, tau + b, mu + b, opts,
+                             off(true_x, b * P), off(x_init, b * P), off(x_out, b * P), off(objective, b * (K + 1)),
+                             off(distance, b * K), off(times, b * (K + 1)), off(mses, b * (K + 1)), off(numA, b),
+                             off(numAt, b), off(n_outer, b), SBTV_HOST_PTRS);
+    });
+}
+
+int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const sbtv_sapg_opts *op,
+                                const double *x0, const double *noise, double *thetas, double *ps, double *sigmas,
+                                double *logpi, double *logpi_wu, double *gx, double *grads, double *eb, double *x_last) {
+    if (!g) return SBTV_ERR_BADARG;
+    if (!y || !op || n_items < 1 || M < 2 || N < 2) return gfail(g, SBTV_ERR_BADARG, "SAPG_algorithm_sharded: missing required argument");
+    const int ns = std::min((int)g->ctxs.size(), n_items);
+    g->active = ns;
+    g->rv.reset(ns);
+    for (auto &it : g->iter) it = 0;
+    const bool shared = op->share_gradients != 0;
+    const size_t P = (size_t)M * N, S = (size_t)(op->samples > 0 ? op->samples : 0), W = (size_t)(op->warmup > 0 ? op->warmup : 1);
+    const size_t steps = (size_t)(op->warmup > 1 ? op->warmup - 1 : 0) + (S > 0 ? S - 1 : 0);
+    auto off = [](auto *p, size_t o) { return p ? p + o : p; };
+    std::vector<ShardUser> users(ns);
+    return run_shards(g, ns, [&](int r) -> int {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        const size_t b = (size_t)lo, nb = (size_t)(hi - lo);
+        sbtv_sapg_opts o = *op;
+        o.chain_offset = op->chain_offset + lo;          // chain b of a call draws the Philox stream chain_offset + b
+        // injected noise is step-major over ALL chains: [step][chain][P] -> this shard's [step][local chain][P]
+        std::vector<double> nz;
+        const double *nzp = nullptr;
+        if (noise) {
+            if (ns == 1) {
+                nzp = noise;
+            } else {
+                nz.resize(steps * nb * P);
+                for (size_t s = 0; s < steps; ++s)
+                    memcpy(nz.data() + s * nb * P, noise + (s * (size_t)n_items + b) * P, sizeof(double) * nb * P);
+                nzp = nz.data();
+            }
+        }
+        users[r] = ShardUser{g, r};
+        const bool coll = shared && ns > 1;
+        return sbtv_SAPG_algorithm(g->ctxs[r], shared ? y : y + b * P, M, N, (int)nb, &o, off(x0, b * P), nzp,
+                                   off(thetas, b * S), off(ps, b * 2 * S), off(sigmas, b * S), off(logpi, b * S),
+                                   off(logpi_wu, b * W), off(gx, b * S), off(grads, b * 4 * S), off(eb, b * 4),
+                                   off(x_last, b * P),
+                                   coll ? reinterpret_cast<sbtv_allreduce_fn>(&group_allreduce) : nullptr,
+                                   coll ? &users[r] : nullptr, SBTV_HOST_PTRS | (coll ? SBTV_REDUCE_DEVICE : 0));
+    });
+}
+
+}  // extern "C"

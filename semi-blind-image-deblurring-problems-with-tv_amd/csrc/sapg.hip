@@ -227,6 +227,9 @@ __global__ __launch_bounds__(256) void sapg_update_kernel(SapgDev u, int phase) 
         __syncthreads();
     }
     if (!(phase & SAPG_PH_UPDATE)) return;
+    // a rank whose iteration failed locally contributes {0, 0, 0, 0, 0 chains, 1}: the flag is latched (red[6] is outside
+    // the six reduced doubles) and the host returns SBTV_ERR_PEER when it next looks at the device
+    if (u.shared && tid == 0 && u.red[5] != 0.0) u.red[6] = 1.0;
     const double delta = u.delta[ii];
     for (int b = tid; b < B; b += 256) {
         SapgChain c = u.chain[b];
@@ -1149,6 +1152,15 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         const size_t bs = (size_t)batch * samples;
         u.tr_theta = tr_d; u.tr_sigma = tr_d + bs; u.tr_logpi = tr_d + 2 * bs; u.tr_gx = tr_d + 3 * bs;
         u.tr_p = tr_d + 4 * bs; u.tr_grads = tr_d + 6 * bs; u.tr_wu = tr_d + 10 * bs;
+        // In-stream collective (SBTV_REDUCE_DEVICE): the host runs up to 1024 iterations ahead of the device, so a rank
+        // that fails locally cannot simply return - its peers have already enqueued, or will enqueue, one all-reduce per
+        // remaining iteration and would wait for it inside the collective.  Such a rank keeps calling reduce_fn once per
+        // remaining iteration with {0, 0, 0, 0, 0 chains, 1 failed} and only then returns its error; the peers latch the
+        // flag on the device (red[6]) and return SBTV_ERR_PEER at their next synchronisation.  Only when reduce_fn
+        // itself fails does a rank return at once.
+        bool collective_done = false, reduce_broken = false;
+        int local_rc = 0;
+        std::string local_err;
         auto update = [&](int phase) -> int {
             hipLaunchKernelGGL(sapg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, u, phase);
             SBTV_HIP(ctx, hipGetLastError());
@@ -1183,8 +1195,11 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
                 SBTV_TRY(update(SAPG_PH_GRADS | SAPG_PH_UPDATE));
             } else {
                 SBTV_TRY(update(SAPG_PH_GRADS));
-                if (reinterpret_cast<sbtv_allreduce_dev_fn>(reduce_fn)(reduce_user, red_d, 6, (void *)ctx->stream) != 0)
+                if (reinterpret_cast<sbtv_allreduce_dev_fn>(reduce_fn)(reduce_user, red_d, 6, (void *)ctx->stream) != 0) {
+                    reduce_broken = true;              // the collective itself failed: nothing left to keep in step with
                     return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: reduce_fn failed");
+                }
+                collective_done = true;
                 SBTV_TRY(update(SAPG_PH_UPDATE));
             }
             // the prox's stop rule has been applied by the update kernel: re-run the steps up to an early stop
@@ -1244,11 +1259,52 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         std::vector<double> logpi0(batch);
         for (int b = 0; b < batch; ++b) logpi0[b] = log_pi(b, theta[b], sig2[b]);                  // :131
         SBTV_TRY(do_prox(false));                                      // proxGX = proxG(X, thetas(1))   (:134)
+        const bool in_stream = shared && reduce_dev;
+        if (in_stream) SBTV_HIP(ctx, hipMemsetAsync(red_d, 0, sizeof(double) * 8, ctx->stream));
+        auto peer_failed = [&]() -> int {          // after a synchronisation: has any rank reported a failure?
+            if (!in_stream) return 0;
+            double latch = 0.0;
+            SBTV_HIP(ctx, hipMemcpy(&latch, red_d + 6, sizeof(double), hipMemcpyDeviceToHost));
+            return latch != 0.0 ? fail(ctx, SBTV_ERR_PEER, "SAPG_algorithm: another rank reported an error through reduce_fn") : 0;
+        };
+        // test hook: SBTV_TEST_FAIL_SAPG="ii:chain_offset" makes the call whose first chain is `chain_offset` fail locally
+        // at SAPG iteration ii (how tests exercise the failure protocol of the in-stream collective)
+        int inject_ii = -1;
+        if (const char *e = getenv("SBTV_TEST_FAIL_SAPG")) {
+            int a = 0, b = 0;
+            if (sscanf(e, "%d:%d", &a, &b) == 2 && b == op->chain_offset) inject_ii = a;
+        }
         for (int ii = 2; ii <= samples; ++ii) {
-            bool replayed = false;
-            if (ii >= 3) SBTV_TRY(replay(&g_main, true, &replayed));
-            if (!replayed) SBTV_TRY(enqueue_iteration(true, params_move && ii > 2, false));
-            if ((ii & 1023) == 0) SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            collective_done = false;
+            if (local_rc == 0) {
+                bool replayed = false;
+                int rc = (ii == inject_ii) ? fail(ctx, SBTV_ERR_NOMEM, "SAPG_algorithm: injected failure (SBTV_TEST_FAIL_SAPG)") : 0;
+                if (rc == 0 && ii >= 3) rc = replay(&g_main, true, &replayed);
+                if (rc == 0 && !replayed) rc = enqueue_iteration(true, params_move && ii > 2, false);
+                if (rc != 0) {
+                    if (!in_stream || reduce_broken) return rc;
+                    local_rc = rc;
+                    local_err = ctx->err;
+                }
+            }
+            if (local_rc != 0 && !collective_done) {
+                static const double failed_vec[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+                if (hipMemcpyAsync(red_d, failed_vec, sizeof(failed_vec), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                    reinterpret_cast<sbtv_allreduce_dev_fn>(reduce_fn)(reduce_user, red_d, 6, (void *)ctx->stream) != 0)
+                    break;
+            }
+            if ((ii & 1023) == 0) {
+                SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (local_rc == 0) SBTV_TRY(peer_failed());
+            }
+        }
+        if (local_rc != 0) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return fail(ctx, local_rc, local_err);
+        }
+        if (in_stream) {
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SBTV_TRY(peer_failed());
         }
         // ---- traces, EB means (:258-284), last sample
         std::vector<double> tr(ntr);

@@ -125,6 +125,7 @@ struct sbtv_ctx {
     std::map<std::string, sbtv::DevBuf> ws;   // named device workspaces (grow-only)
     std::map<int, double2 *> twiddles;         // n -> exp(-2 pi i k / n), k < n
     std::map<int, double2 *> any_axes;         // n -> Bluestein tables of the arbitrary-size path (fft_any.inc)
+    bool any_attr_done = false;                // its kernel's dynamic-LDS limit has been raised on this context's device
     void *pinned = nullptr;                    // pinned host staging for scalar read-back
     size_t pinned_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -106,6 +106,16 @@ SIGNATURES = {
     "sbtv_max_eigenval": (_I, [_P, _P, _I, _P, _I, _I, _D, _I, _P, _P, _I]),
     "sbtv_PSNR": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
     "sbtv_MSE": (_I, [_P, _P, _P, _I, _I, _I, _P, _I]),
+    "sbtv_group_create": (_I, [C.POINTER(_I), _I, C.POINTER(_P)]),
+    "sbtv_group_destroy": (_I, [_P]),
+    "sbtv_group_size": (_I, [_P]),
+    "sbtv_group_ctx": (_P, [_P, _I]),
+    "sbtv_group_last_error": (C.c_char_p, [_P]),
+    "sbtv_group_shard_of": (_I, [_P, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "sbtv_SALSA_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.POINTER(sbtv_salsa_opts), _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P, _P]),
+    "sbtv_SAPG_algorithm_sharded": (_I, [_P, _P, _I, _I, _I, C.POINTER(sbtv_sapg_opts), _P, _P, _P, _P, _P, _P, _P, _P,
+                                         _P, _P, _P]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
     "sbtv_last_host_stats": (_I, [_P, C.POINTER(_D)]),
@@ -243,6 +253,46 @@ class Context:
         self.check(self.lib.sbtv_memcpy_d2h(self.h, vptr(buf), p, need))
         a = np.transpose(buf, (0, 2, 1))
         return a[0] if batch == 1 else a
+
+
+class Group:
+    """Several GPUs behind this one process (sbtv_group): pass it as `ctx=` to SALSA_v2 or the SAPG_algorithm_*
+    functions with HOST (NumPy) images; items are dealt to the devices in contiguous blocks.  An ordinal may repeat
+    ("virtual shards" on one GPU)."""
+    is_group = True
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = _P()
+        rc = self.lib.sbtv_group_create(devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise SbtvError(rc, self.lib.sbtv_last_error(None).decode())
+        self.h = h
+        self.devices = [int(d) for d in devices]
+
+    def __len__(self):
+        return self.lib.sbtv_group_size(self.h)
+
+    def shard_of(self, n_items, item):
+        s, f, c = _I(0), _I(0), _I(0)
+        self.check(self.lib.sbtv_group_shard_of(self.h, int(n_items), int(item), C.byref(s), C.byref(f), C.byref(c)))
+        return dict(shard=s.value, first=f.value, count=c.value)
+
+    def check(self, rc, flags=0):
+        if rc != 0:
+            raise SbtvError(rc, self.lib.sbtv_group_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sbtv_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def switches():

@@ -120,10 +120,19 @@ def SALSA_v2(y, A, tau, *varargin, ctx=None, **kw):
     tau_a, tau_p = L.dvec(tau, B)
     mu_a, mu_p = L.dvec(mu, B)
     vp = L.vptr
-    ctx.check(ctx.lib.sbtv_SALSA_v2(ctx.h, yi.ptr, M, N, B, vp(taps), A.taille, tau_p, mu_p, C.byref(so),
-                                    ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr,
-                                    vp(objective), vp(distance), vp(times), vp(mses) if ti else None,
-                                    numA, numAt, nout, yi.flags), yi.flags)
+    if getattr(ctx, "is_group", False):
+        # several GPUs behind this process (sbtv.Group): images dealt to the devices in contiguous blocks
+        if yi.flags != L.SBTV_HOST_PTRS:
+            raise ValueError("a sbtv.Group takes host (NumPy) images")
+        ctx.check(ctx.lib.sbtv_SALSA_v2_sharded(ctx.h, yi.ptr, M, N, B, vp(taps), A.taille, tau_p, mu_p, C.byref(so),
+                                                ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr,
+                                                vp(objective), vp(distance), vp(times), vp(mses) if ti else None,
+                                                numA, numAt, nout))
+    else:
+        ctx.check(ctx.lib.sbtv_SALSA_v2(ctx.h, yi.ptr, M, N, B, vp(taps), A.taille, tau_p, mu_p, C.byref(so),
+                                        ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr,
+                                        vp(objective), vp(distance), vp(times), vp(mses) if ti else None,
+                                        numA, numAt, nout, yi.flags), yi.flags)
     sq = (y.dim() == 2) if yi.torch else yi.squeeze
     x = L.images_result(xo, sq)
     n = np.array(nout[:])

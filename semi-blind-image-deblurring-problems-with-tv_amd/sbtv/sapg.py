@@ -160,9 +160,20 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
             xl = L.Images(torch.empty((nch, N, M), dtype=torch.float64, device=yi.t.device).permute(0, 2, 1))
         else:
             xl = L.Images(np.zeros((nch, M, N)))
-    ctx.check(ctx.lib.sbtv_SAPG_algorithm(ctx.h, yptr, M, N, nch, C.byref(o), x0i.ptr if x0i else None, nz_ptr,
-                                          vp(thetas), vp(ps), vp(sigmas), vp(logpi), vp(logpi_wu), vp(gx), vp(grads),
-                                          vp(eb), xl.ptr, cb, None, yi.flags | xflags), yi.flags)
+    if getattr(ctx, "is_group", False):
+        # several GPUs behind this process (sbtv.Group): images / chains dealt to the devices in contiguous blocks; with
+        # share_gradients the six gradient sums are exchanged in-process, in-stream (no reduce_fn needed or accepted)
+        if yi.flags != L.SBTV_HOST_PTRS or (noise is not None and L._is_torch(noise)):
+            raise ValueError("a sbtv.Group takes host (NumPy) images")
+        if reduce_fn is not None or reduce_dev_fn is not None or host_loop:
+            raise ValueError("a sbtv.Group exchanges the shared gradients itself: no reduce_fn / host_loop")
+        ctx.check(ctx.lib.sbtv_SAPG_algorithm_sharded(ctx.h, yptr, M, N, nch, C.byref(o), x0i.ptr if x0i else None, nz_ptr,
+                                                      vp(thetas), vp(ps), vp(sigmas), vp(logpi), vp(logpi_wu), vp(gx),
+                                                      vp(grads), vp(eb), xl.ptr))
+    else:
+        ctx.check(ctx.lib.sbtv_SAPG_algorithm(ctx.h, yptr, M, N, nch, C.byref(o), x0i.ptr if x0i else None, nz_ptr,
+                                              vp(thetas), vp(ps), vp(sigmas), vp(logpi), vp(logpi_wu), vp(gx), vp(grads),
+                                              vp(eb), xl.ptr, cb, None, yi.flags | xflags), yi.flags)
     results = []
     for b in range(nch):
         r = dict(theta_EB=eb[b, 0], sigma_EB=eb[b, 3], last_samp=S, thetas=thetas[b], sigmas=sigmas[b],

@@ -86,12 +86,12 @@ def test_a_wrapper_vectorised_adaptor_errors():
     assert g.shape == (6, 1) and np.allclose(g[:, 0], 2 * np.arange(6.0))
 
 
-def _build_c_host(tmp_path):
+def _build_c_host(tmp_path, name="c_host"):
     import subprocess
-    exe = str(tmp_path / "c_host")
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd", "lib")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "c_host.c"), "-L" + libdir, "-lsbtv", "-lm",
+                    os.path.join(ROOT, "examples", name + ".c"), "-L" + libdir, "-lsbtv", "-lm",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     return exe
 
@@ -100,6 +100,7 @@ def test_plain_c_host_compiles_and_links(tmp_path):
     """The boundary is usable from C without Python or torch: examples/c_host.c builds against include/sbtv.h
     and links libsbtv.so (running it needs the GPU: tests/test_gpu_c_host.py)."""
     assert os.path.exists(_build_c_host(tmp_path))
+    assert os.path.exists(_build_c_host(tmp_path, "c_host_multi"))      # the single-process multi-GPU host (sbtv_group)
 
 
 @pytest.mark.parametrize("kind", ["gaussian", "moffat", "laplace"])

@@ -1,0 +1,181 @@
+"""GPU: several devices behind ONE host process through the C-ABI (`sbtv_group`, include/sbtv.h).
+
+The reference's host is a single MATLAB process (run_Gaussian_demo.m:199,229), so multi-GPU has to be reachable
+without `torch.distributed`.  A one-GPU box exercises everything with "virtual shards": a group whose entries all
+name device 0 (the survey's N-shards-on-one-device mode).  Independent images must come out bit for bit as from the
+single-context call; chains with shared gradients reproduce the single-call traces up to the order of the six-double
+sum (shard sums first)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def group3():
+    import sbtv
+    g = sbtv.Group([0, 0, 0])
+    yield g
+    g.close()
+
+
+def _salsa_problem(n, M=64, N=48):
+    import sbtv_oracle as o
+    xs, ys, taus = [], [], []
+    for b in range(n):
+        x = synth_image(M, N, 20 + b)
+        st = o.demo_setup("gaussian", x, np.random.default_rng(b).standard_normal(x.shape), evMax=1.0)
+        xs.append(x)
+        ys.append(st["y"])
+        taus.append(0.03 * st["sigma"] ** 2 * (1 + 0.2 * b))
+    return np.stack(xs), np.stack(ys), taus
+
+
+def test_group_block_partition(group3):
+    assert len(group3) == 3
+    # contiguous blocks, remainder to the first shards, only min(n, items) shards used
+    assert [group3.shard_of(5, i)["shard"] for i in range(5)] == [0, 0, 1, 1, 2]
+    assert group3.shard_of(5, 4) == dict(shard=2, first=4, count=1)
+    assert [group3.shard_of(2, i)["shard"] for i in range(2)] == [0, 1]
+
+
+def test_salsa_sharded_is_bit_equal_to_single_context(ctx, group3):
+    import sbtv
+    xs, ys, taus = _salsa_problem(5)
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    args = ("MU", 0.003, "AT", A.T, "LS", A.LS(0.003), "True_x", xs, "ToleranceA", 1e-4, "MAXITERA", 80,
+            "TVINITIALIZATION", 1, "TViters", 10)
+    one = sbtv.SALSA_v2(ys, A, taus, *args, ctx=ctx)
+    shd = sbtv.SALSA_v2(ys, A, taus, *args, ctx=group3)
+    np.testing.assert_array_equal(shd[0], one[0])
+    np.testing.assert_array_equal(shd[1], one[1])
+    for b in range(5):
+        np.testing.assert_array_equal(shd[3][b], one[3][b])      # objective traces (and so the stopping iterations)
+        np.testing.assert_array_equal(shd[4][b], one[4][b])
+        np.testing.assert_array_equal(shd[6][b], one[6][b])
+    assert len({len(o_) for o_ in one[3]}) > 1                      # images stop at different iterations
+
+
+def test_salsa_sharded_fewer_items_than_shards(ctx, group3):
+    import sbtv
+    xs, ys, taus = _salsa_problem(2)
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    args = ("MU", 0.003, "AT", A.T, "LS", A.LS(0.003), "ToleranceA", 1e-4, "MAXITERA", 30, "TVINITIALIZATION", 1, "TViters", 10)
+    one = sbtv.SALSA_v2(ys, A, taus[:2], *args, ctx=ctx)
+    shd = sbtv.SALSA_v2(ys, A, taus[:2], *args, ctx=group3)
+    np.testing.assert_array_equal(shd[0], one[0])
+
+
+def _sapg_op(kind, st, samples, warmup, burnIn):
+    from test_gpu_sapg_fista import _op_struct
+    return _op_struct(kind, st, samples, warmup, burnIn)
+
+
+def test_sapg_sharded_independent_images_bit_equal_with_philox(ctx, group3):
+    """configs[3] pattern: independent images, device Philox noise: image i draws stream chain_offset + i whatever the
+    sharding, so the group's result equals the single-context batch bit for bit."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    sts = [o.demo_setup("laplace", synth_image(M, N, 30 + b), np.random.default_rng(b).standard_normal((M, N)), evMax=0.99)
+           for b in range(4)]
+    op, c, names = _sapg_op("laplace", sts[0], 9, 4, 5)
+    op["seed"] = 7
+    y = np.stack([st["y"] for st in sts])
+    one = sbtv.SAPG_algorithm_laplace(y, op, c, ctx=ctx)[-1]
+    shd = sbtv.SAPG_algorithm_laplace(y, op, c, ctx=group3)[-1]
+    for b in range(4):
+        for key in ("thetas", "bs", "sigmas", "logPiTraceX", "gXTrace", "Xlast_sample", "logPiTrace_WU"):
+            np.testing.assert_array_equal(shd[b][key], one[b][key], err_msg=f"{b}:{key}")
+    assert not np.array_equal(one[0]["thetas"], one[1]["thetas"])
+
+
+@pytest.mark.parametrize("nshards", [2, 4])
+def test_sapg_sharded_shared_chains_match_single_call_and_oracle(ctx, nshards):
+    """configs[4] pattern: four chains on one image with `G = mean(g_*)` (SAPG_algorithm_moffat.m:158-173), injected noise:
+    the in-process exchange of the six gradient sums must reproduce the single-context 4-chain call (sum order differs:
+    shard sums first) and the oracle's SAPG_algorithm_shared."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    x = synth_image(M, N, 3)
+    rng = np.random.default_rng(2)
+    st = o.demo_setup("gaussian", x, rng.standard_normal((M, N)), evMax=0.99)
+    C_, samples, warmup, burnIn = 4, 8, 3, 4
+    nz = rng.standard_normal((warmup - 1 + samples - 1, C_, M, N))
+    step = [0] * C_
+
+    def randn(shape, k):
+        z = nz[step[k], k]
+        step[k] += 1
+        return z
+    p_init = (0.5, 0.35)
+    ref = o.SAPG_algorithm_shared(st, C_, samples, warmup, burnIn, randn, p_init=p_init, fix=(False, False))
+    op, c, names = _sapg_op("gaussian", st, samples, warmup, burnIn)
+    for q, nm in enumerate(names):
+        op["fix_" + nm] = 0
+        op[nm + "_init"] = p_init[q]
+    op["chains"] = C_
+    one = sbtv.SAPG_algorithm_Guassian(st["y"], op, c, noise=nz, share_gradients=True, ctx=ctx)[-1]
+    g = sbtv.Group([0] * nshards)
+    try:
+        shd = sbtv.SAPG_algorithm_Guassian(st["y"], op, c, noise=nz, share_gradients=True, ctx=g)[-1]
+    finally:
+        g.close()
+    assert len(shd) == C_
+    for k in range(C_):
+        for key in ("thetas", "sigmas", "w1s", "w2s", "logPiTraceX", "gXTrace"):
+            np.testing.assert_allclose(shd[k][key], one[k][key], rtol=1e-11, err_msg=f"{k}:{key}")
+        np.testing.assert_allclose(shd[k]["Xlast_sample"], one[k]["Xlast_sample"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(shd[k]["thetas"], ref["thetas"], rtol=1e-9)
+        np.testing.assert_allclose(shd[k]["w1s"], ref["ps"][0], rtol=1e-8)
+        np.testing.assert_allclose(shd[k]["logPiTraceX"], ref["logPiTraceX"][k], rtol=1e-9)
+        np.testing.assert_array_equal(shd[k]["thetas"], shd[0]["thetas"])       # every shard applied the same update
+    assert ref["ps"][0][-1] != ref["ps"][0][0]
+
+
+def test_sapg_sharded_shared_chains_philox_streams_do_not_depend_on_sharding(ctx):
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    st = o.demo_setup("gaussian", synth_image(M, N, 5), np.random.default_rng(1).standard_normal((M, N)), evMax=0.99)
+    op, c, names = _sapg_op("gaussian", st, 7, 3, 4)
+    op["chains"], op["seed"] = 4, 11
+    one = sbtv.SAPG_algorithm_Guassian(st["y"], op, c, share_gradients=True, ctx=ctx)[-1]
+    g = sbtv.Group([0, 0])
+    try:
+        shd = sbtv.SAPG_algorithm_Guassian(st["y"], op, c, share_gradients=True, ctx=g)[-1]
+    finally:
+        g.close()
+    for k in range(4):
+        np.testing.assert_allclose(shd[k]["thetas"], one[k]["thetas"], rtol=1e-11)
+        np.testing.assert_allclose(shd[k]["Xlast_sample"], one[k]["Xlast_sample"], rtol=1e-9, atol=1e-9)
+
+
+def test_sapg_sharded_failing_shard_is_reported_and_nobody_hangs(ctx):
+    """A shard whose iteration fails locally (test hook SBTV_TEST_FAIL_SAPG = "iteration:first chain of the call") keeps
+    the in-stream exchange in step until the loop ends; the call returns ITS error, not SBTV_ERR_PEER, and returns."""
+    import sbtv
+    import sbtv_oracle as o
+    M = N = 32
+    st = o.demo_setup("gaussian", synth_image(M, N, 5), np.random.default_rng(1).standard_normal((M, N)), evMax=0.99)
+    op, c, names = _sapg_op("gaussian", st, 12, 2, 4)
+    op["chains"] = 4
+    g = sbtv.Group([0, 0])
+    os.environ["SBTV_TEST_FAIL_SAPG"] = "5:2"            # the second shard's call starts at chain 2
+    try:
+        with pytest.raises(sbtv.SbtvError) as ei:
+            sbtv.SAPG_algorithm_Guassian(st["y"], op, c, share_gradients=True, ctx=g)
+        assert "injected failure" in str(ei.value) and "shard 1" in str(ei.value)
+        assert ei.value.code == -11
+        del os.environ["SBTV_TEST_FAIL_SAPG"]
+        # the group is usable afterwards
+        res = sbtv.SAPG_algorithm_Guassian(st["y"], op, c, share_gradients=True, ctx=g)[-1]
+        assert len(res) == 4 and np.all(np.isfinite(res[0]["thetas"]))
+    finally:
+        os.environ.pop("SBTV_TEST_FAIL_SAPG", None)
+        g.close()
