@@ -452,21 +452,34 @@ int sbtv_diag_workspace(sbtv_ctx *ctx, const char *name, void **dptr, size_t *by
 int sbtv_diag_switches(char *buf, size_t cap) {
     static const char *const names[] = {
         "SBTV_CANARY", "SBTV_COLLECT_RIDE", "SBTV_EXACT", "SBTV_FFT_WAVE", "SBTV_FISTA_FUSED_STEP", "SBTV_FISTA_LAG",
-        "SBTV_FUSED_VARIANT", "SBTV_GRAPH", "SBTV_INLINE_CTRL", "SBTV_PROX_PIPE", "SBTV_PROX_SPEC", "SBTV_ROWS_KERNEL",
-        "SBTV_ROWS_PIPE", "SBTV_ROWS_RK", "SBTV_ROWS_V", "SBTV_SAPG_DEFER", "SBTV_SAPG_FUSED_MYULA", "SBTV_SAPG_HOST",
-        "SBTV_SINGLE_STEP", "SBTV_SPIN", "SBTV_TAG_SPIN_US", "SBTV_U_TILED"};
+        "SBTV_FUSED_VARIANT", "SBTV_GRAPH", "SBTV_INLINE_CTRL", "SBTV_PROX_SPEC", "SBTV_SAPG_DEFER",
+        "SBTV_SAPG_FUSED_MYULA", "SBTV_SAPG_HOST", "SBTV_SINGLE_STEP", "SBTV_SPIN", "SBTV_TAG_SPIN_US", "SBTV_ADMM_EXACT"};
+    // variants that lost their measurements: only the lab build (make lab, -DSBTV_LAB) carries the kernels and reads these
+    static const char *const lab_names[] = {"SBTV_PROX_PIPE", "SBTV_ROWS_KERNEL", "SBTV_ROWS_PIPE", "SBTV_ROWS_RK",
+                                            "SBTV_ROWS_V", "SBTV_U_TILED"};
     if (!buf || cap == 0) return SBTV_ERR_BADARG;
     std::string s;
     int nset = 0;
+    auto add = [&](const char *n, const char *e, const char *note) {
+        s += (nset++ ? " " : "");
+        s += n;
+        s += "=";
+        s += e;
+        s += note;
+    };
     for (const char *n : names)
+        if (const char *e = getenv(n)) add(n, e, "");
+    for (const char *n : lab_names)
         if (const char *e = getenv(n)) {
-            s += (nset++ ? " " : "");
-            s += n;
-            s += "=";
-            s += e;
+#ifdef SBTV_LAB
+            add(n, e, "");
+#else
+            add(n, e, "(ignored:lab-build-only)");
+            --nset;                                   // does not change which kernels run
+#endif
         }
 #ifdef SBTV_LAB
-    s += (nset ? " " : "");
+    s += (s.empty() ? "" : " ");
     s += "[build: SBTV_LAB]";
 #endif
     if (s.size() + 1 > cap) s.resize(cap - 1);

@@ -802,31 +802,45 @@ static inline bool wave_enabled() {
 }
 // row pass of the tiled sizes: the wave-granular kernel (SBTV_ROWS_KERNEL=wave) or the workgroup kernel (default: in
 // the solver loops, where H / Y come from HBM, it is the faster one - profiles/r02_fft_insitu.md)
+// (lab build only: it lost in the loop, profiles/r02_fft_lab.md; the default library does not carry the kernel)
 static inline bool rows_wave() {
+#ifdef SBTV_LAB
     static const bool on = [] {
         const char *e = getenv("SBTV_ROWS_KERNEL");
         return e && e[0] == 'w' && e[1] == 'a';
     }();
     return on;
+#else
+    return false;
+#endif
 }
 // operator spectra tiled like S (default) or column-major U[l][k] (SBTV_U_TILED=0, the round-1 layout) in the wave mode
 static inline bool u_tiled_wanted() {
+#ifdef SBTV_LAB
     static const bool on = [] {
         const char *e = getenv("SBTV_U_TILED");
         return !(e && e[0] == '0');
     }();
     return on;
+#else
+    return true;
+#endif
 }
 // software-pipelined row pass (rows_pipe_kernel) for the sizes of the wave mode; SBTV_ROWS_PIPE=0: the workgroup row
 // kernel on the tiled layout instead (A/B runs: profiles/r02_rows_pipe.md)
 static inline bool rows_pipe(int log2n) {
+    (void)log2n;
+#ifdef SBTV_LAB
     static const bool on = [] {
         const char *e = getenv("SBTV_ROWS_PIPE");
         return !(e && e[0] == '0');
     }();
-    (void)log2n;
     return on;
+#else
+    return true;
+#endif
 }
+#ifdef SBTV_LAB
 static inline int rows_v(int dflt) {     // values per thread of the wave-granular row pass (tuning hook: SBTV_ROWS_V=8|16)
     static const int v = [] {
         const char *e = getenv("SBTV_ROWS_V");
@@ -834,6 +848,7 @@ static inline int rows_v(int dflt) {     // values per thread of the wave-granul
     }();
     return (v == 8 || v == 16) ? v : dflt;
 }
+#endif
 
 int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
     if (M < 2 || N < 2 || M > 4096 || N > 4096)
@@ -1050,10 +1065,14 @@ int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double
 // rows per workgroup of the row pass: 4 (64-byte segments) from N = 512 on, 8 below; N = 2048 may use
 // 2 (SBTV_ROWS_RK=2: 512-thread workgroups, two per CU so load / FFT / store phases overlap)
 static inline int rows_rk(const FftPlan &pl) {
+#ifdef SBTV_LAB
     static const int rk2048 = [] {
         const char *e = getenv("SBTV_ROWS_RK");
         return (e && atoi(e) == 2) ? 2 : 4;
     }();
+#else
+    const int rk2048 = 4;
+#endif
     const int N = pl.N;
     if (N == 4096) return 2;                 // two 4096-point rows fill the LDS exchange buffer (128 KB)
     if (N == 2048) return rk2048;
@@ -1069,6 +1088,7 @@ int fft_rows_blocks(const FftPlan &pl) {
     return pl.n1 / rows_rk(pl);
 }
 
+#ifdef SBTV_LAB
 template <int L, int V>
 static void launch_rows_wave(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
     const dim3 grid(pl.n1 / 2, pl.batch), block(2 * ((1 << L) / V));
@@ -1085,6 +1105,7 @@ static void launch_rows_wave(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams 
         default: break;
     }
 }
+#endif
 
 template <int L>
 static void launch_rows_pipe(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
@@ -1157,12 +1178,15 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
             SBTV_HIP(ctx, hipGetLastError());
             return 0;
         }
+#ifdef SBTV_LAB
         // the workgroup row kernel on the tiled layout: 4 rows x 4 columns = 256 contiguous bytes per access
         if (L == 11) launch_rows<11, 4, true>(ctx, pl, p);
         else launch_rows<10, 4, true>(ctx, pl, p);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
+#endif
     }
+#ifdef SBTV_LAB
     if (pl.wave) {
         // values per thread: 16 (radix-16 stages) at N = 2048, 8 at N = 1024 (measured: profiles/r02_fft_lab.md)
         const int V = rows_v(L == 11 ? 16 : 8);
@@ -1176,6 +1200,7 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
     }
+#endif
     if (pl.N >= 512) {
         switch (L) {
             case 9:
@@ -1184,8 +1209,11 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
                 break;
             case 10: launch_rows<10, 4>(ctx, pl, p); break;
             case 11:
+#ifdef SBTV_LAB
                 if (rows_rk(pl) == 2) launch_rows<11, 2>(ctx, pl, p);
-                else launch_rows<11, 4>(ctx, pl, p);
+                else
+#endif
+                    launch_rows<11, 4>(ctx, pl, p);
                 break;
             case 12: launch_rows<12, 2>(ctx, pl, p); break;
             default: break;

@@ -373,7 +373,11 @@ __device__ __forceinline__ void fused_tl(int slot) {
 #endif
 #include "tv_fused.inc"
 #include "tv_fused1.inc"
-#include "tv_pipe.inc"
+#ifdef SBTV_LAB
+#include "tv_pipe.inc"      // streaming pipeline kernel: measured and lost (profiles/r02_chambolle_variants.md); lab build only
+#else
+constexpr int PK = 10;      // (the pipeline kernel's iterations per launch; the plan code below keeps its arithmetic)
+#endif
 
 // Stop rule after a fused launch of `steps_arg` iterations (see the kernel header).
 __global__ __launch_bounds__(64 * FSMAX) void chambolle_fused_ctrl_kernel(ProxCtrl *__restrict__ ctrl,
@@ -659,11 +663,17 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
         std::call_once(env_once, [] {
             if (const char *e = getenv("SBTV_FUSED_VARIANT")) {   // tuning hook: "cj,nw,minw[,rows_per_lane]"
                 int cj = 0, nw = 0, mw = 0, rpl = 2;
+#ifdef SBTV_LAB
                 static const int known[][4] = {{8, 4, 2, 2}, {8, 8, 2, 2}, {8, 8, 1, 2}, {8, 4, 3, 2}, {6, 8, 3, 2}, {12, 4, 2, 2}, {16, 4, 1, 2},
                                                {4, 8, 2, 2}, {4, 16, 2, 2}, {8, 6, 2, 2}, {4, 8, 3, 2}, {4, 8, 4, 2},
                                                {6, 8, 4, 2}, {6, 8, 2, 2}, {5, 8, 4, 2},
                                                {4, 8, 6, 1}, {4, 8, 5, 1}, {4, 8, 4, 1}, {8, 4, 6, 1}, {8, 8, 4, 1},
                                                {8, 4, 4, 1}, {6, 8, 6, 1}, {6, 8, 4, 1}};
+#else
+                // the default build carries the two geometries the plans choose themselves (128-row tiles, and 64-row
+                // tiles for small grids); the others lost on MI355X and live in the lab build (make lab)
+                static const int known[][4] = {{4, 8, 4, 2}, {4, 8, 4, 1}};
+#endif
                 bool ok = false;
                 if (sscanf(e, "%d,%d,%d,%d", &cj, &nw, &mw, &rpl) >= 3)
                     for (auto &k4 : known) ok = ok || (k4[0] == cj && k4[1] == nw && k4[2] == mw && k4[3] == rpl);
@@ -708,14 +718,23 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
             const char *e = getenv("SBTV_PROX_PIPE");
             return e ? atoi(e) : -1;
         }();
+#ifdef SBTV_LAB
         const int nbands = (M + PCI - 1) / PCI;
+#else
+        const int nbands = (M + 105) / 106;
+#endif
         int nseg = 256 / (nbands * batch);
         if (nseg < 1) nseg = 1;
         if (nseg > N / 80) nseg = N / 80;
         if (nseg < 1) nseg = 1;
         const int seglen = (N + nseg - 1) / nseg;
         nseg = (N + seglen - 1) / seglen;
+#ifndef SBTV_LAB
+        (void)env_pipe;
+        if (false) {
+#else
         if (env_pipe == 1 && (M % 2 == 0) && !g_fused_forced) {
+#endif
             pl->pipe = 1;
             pl->nbands = nbands;
             pl->nseg = nseg;
@@ -860,6 +879,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                     spec_off += steps;
                 }
             }
+#ifdef SBTV_LAB
             if (pl.pipe) {
                 launched = true;
                 if (g_fused.fast)
@@ -871,6 +891,7 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                                        pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.nbands, pl.nseg, pl.seglen, pl.fnblk,
                                        steps, redo, f_out, write_f, pl.counters, kflags);
             }
+#endif
 #define SBTV_FUSED_CASE(CJ_, NW_, MW_)                                                                               \
     if (!pl.pipe && pl.rpl == 2 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {             \
         launched = true;                                                                                             \
@@ -883,6 +904,8 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
                                pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);              \
     }
+            SBTV_FUSED_CASE(4, 8, 4)
+#ifdef SBTV_LAB
             SBTV_FUSED_CASE(8, 4, 2)
             SBTV_FUSED_CASE(8, 8, 2)
             SBTV_FUSED_CASE(8, 8, 1)
@@ -894,10 +917,10 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
             SBTV_FUSED_CASE(4, 16, 2)
             SBTV_FUSED_CASE(8, 6, 2)
             SBTV_FUSED_CASE(4, 8, 3)
-            SBTV_FUSED_CASE(4, 8, 4)
             SBTV_FUSED_CASE(6, 8, 4)
             SBTV_FUSED_CASE(6, 8, 2)
             SBTV_FUSED_CASE(5, 8, 4)
+#endif
 #undef SBTV_FUSED_CASE
 #define SBTV_FUSED1_CASE(CJ_, NW_, MW_)                                                                              \
     if (!pl.pipe && pl.rpl == 1 && pl.cj == CJ_ && pl.nw == NW_ && pl.minw == MW_) {             \
@@ -911,14 +934,16 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
                                pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);                         \
     }
+            SBTV_FUSED1_CASE(4, 8, 4)
+#ifdef SBTV_LAB
             SBTV_FUSED1_CASE(4, 8, 6)
             SBTV_FUSED1_CASE(4, 8, 5)
-            SBTV_FUSED1_CASE(4, 8, 4)
             SBTV_FUSED1_CASE(8, 4, 6)
             SBTV_FUSED1_CASE(8, 4, 4)
             SBTV_FUSED1_CASE(8, 8, 4)
             SBTV_FUSED1_CASE(6, 8, 6)
             SBTV_FUSED1_CASE(6, 8, 4)
+#endif
 #undef SBTV_FUSED1_CASE
             // a plan whose geometry matches no compiled variant must not pass silently (nothing was enqueued)
             if (!launched)

@@ -17,6 +17,9 @@ for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the lab build (make -C csrc lab; __graft_entry__.build() makes it too): the default library plus the kernel variants
+# that were measured and lost; child processes select it with SBTV_LIBRARY
+LAB_LIB = os.path.join(PKG, "lib", "libsbtv_lab.so")
 
 
 try:                                      # NumPy may have been imported (by a plugin) before the variables were set

@@ -10,7 +10,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from conftest import LAB_LIB
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAB = {"SBTV_LIBRARY": LAB_LIB}      # variants only the lab build carries
 
 CHILD = r"""
 import json, os, sys
@@ -44,9 +47,10 @@ def test_exact_fast_single_step_and_tile_variants_agree(tmp_path):
     variants = {
         "exact": {"SBTV_EXACT": "1"},                       # IEEE div/sqrt, no FMA contraction
         "single": {"SBTV_SINGLE_STEP": "1"},                # one-iteration kernels (the fallback path)
-        "tile_8_4": {"SBTV_FUSED_VARIANT": "8,4,2"},        # other tile geometry of the fused kernel
-        "tile_16_4": {"SBTV_FUSED_VARIANT": "16,4,1"},
-        "nospec": {"SBTV_FUSED_VARIANT": "4,8,2"},
+        "tile_8_4": dict(LAB, SBTV_FUSED_VARIANT="8,4,2"),  # other tile geometries of the fused kernel (lab build)
+        "tile_16_4": dict(LAB, SBTV_FUSED_VARIANT="16,4,1"),
+        "nospec": dict(LAB, SBTV_FUSED_VARIANT="4,8,2"),
+        "lab_default": dict(LAB),                           # the lab build without any switch = the default kernels
         "rows1": {"SBTV_FUSED_VARIANT": "4,8,4,1"},         # one row per lane (64-row tiles; the default on small grids)
         "rows2": {"SBTV_FUSED_VARIANT": "4,8,4"},           # the 128-row tiles large images get, forced on these small ones
         "inline": {"SBTV_INLINE_CTRL": "1"},                # stop rule applied by the last workgroup of a launch

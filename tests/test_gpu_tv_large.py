@@ -177,7 +177,8 @@ def test_pipeline_kernel_passes_the_prox_parity_suite():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SBTV_PROX_PIPE="1")
+    from conftest import LAB_LIB
+    env = dict(os.environ, SBTV_PROX_PIPE="1", SBTV_LIBRARY=LAB_LIB)      # the pipeline kernel lives in the lab build
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_tv.py"),
                         os.path.join(root, "tests", "test_gpu_tv_large.py"), "-m", "gpu", "-x", "-q", "-k",
                         "not passes_the_prox_parity_suite"],

@@ -126,8 +126,10 @@ def main():
         # in-stream RCCL all-reduce on the library's device buffer (the loop never waits for the host);
         # --host-reduce selects the round-1 host callback (D2H, all-reduce, H2D and a synchronisation per iteration)
         import torch.distributed as tdist0
-        if world > 1 and tdist0.get_backend() != "nccl":
+        if world > 1 and tdist0.get_backend() != "nccl" and not a.all_ranks_on_device0:
             a.host_reduce = True         # gloo stages device tensors through the host anyway: use the host callback
+        # (the one-GPU rehearsal --backend gloo --all-ranks-on-device0 keeps the in-stream device hook, so that the
+        # production callback - ExternalStream + CUDA-array-interface view - is what the rehearsal exercises)
         if a.host_reduce:
             kw = dict(share_gradients=True, reduce_fn=sd.make_allreduce_fn(), ctx=ctx)
         else:
