@@ -262,6 +262,7 @@ struct ProxPlan {
     double *partials;             // [2 sets][batch][FSTRIDE][fnblk] (or [batch][nblk] for the one-iteration kernels)
     size_t part_stride;           // doubles per set
     unsigned *counters;           // [batch] arrival tickets (in-kernel stop-rule path)
+    const int *order;             // [fnblk] workgroup -> tile of the 128-row tile kernel (null: the arithmetic XCD-chunk order)
 };
 int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan, const char *tag = "prox");
 // (Re)initialise the control blocks: k=0, done=0 and the per-image lambda from a

@@ -755,6 +755,42 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     SBTV_TRY(ws_get_t(ctx, (t + ".partials").c_str(), 2 * npart, &pl->partials));
     pl->part_stride = npart;
     // arrival tickets of the in-kernel control path: zero between launches (the last workgroup resets it)
+    // workgroup -> tile table of the 128-row tile kernel on grids of more than one round of workgroups: the XCD chunks
+    // of the arithmetic order (workgroup id mod 8 names the XCD, each XCD walks a contiguous chunk of the tile list), but
+    // inside a chunk the border tiles (boundary selects: ~1.35 x the instructions of an interior tile) come first
+    pl->order = nullptr;
+    {
+        static const bool env_off = [] {
+            const char *e = getenv("SBTV_TILE_ORDER");
+            return e && e[0] == '0';
+        }();
+        const int nt = pl->fnblk;
+        if (!env_off && !pl->pipe && pl->rpl == 2 && nt > 2 * 256) {
+            int *od = nullptr;
+            // one table per shape, built once per context (the name carries the shape)
+            const std::string name = "prox.order." + std::to_string(M) + "x" + std::to_string(N) + "." + std::to_string(pl->cj) +
+                                     "." + std::to_string(pl->nw);
+            const bool built = ctx->ws.find(name) != ctx->ws.end();
+            SBTV_TRY(ws_get_t(ctx, name.c_str(), (size_t)nt, &od));
+            if (!built) {
+                std::vector<int> h(nt);
+                const int q8 = nt >> 3, r8 = nt & 7, ti_n = pl->ftiles_i, tj_n = pl->ftiles_j;
+                for (int x = 0; x < 8; ++x) {
+                    const int c0 = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8), len = q8 + (x < r8 ? 1 : 0);
+                    int o = 0;
+                    for (int pass = 0; pass < 2; ++pass)
+                        for (int t2 = c0; t2 < c0 + len; ++t2) {
+                            const int ti = t2 % ti_n, tj = t2 / ti_n;
+                            const bool border = (ti == 0 || ti == ti_n - 1 || tj == 0 || tj == tj_n - 1);
+                            if (border == (pass == 0)) h[(size_t)(o++) * 8 + x] = t2;      // workgroup id = o * 8 + x
+                        }
+                }
+                SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                SBTV_HIP(ctx, hipMemcpy(od, h.data(), sizeof(int) * nt, hipMemcpyHostToDevice));
+            }
+            pl->order = od;
+        }
+    }
     SBTV_TRY(ws_get_t(ctx, (t + ".counters").c_str(), (size_t)batch, &pl->counters));
     SBTV_HIP(ctx, hipMemsetAsync(pl->counters, 0, sizeof(unsigned) * batch, ctx->stream));
     return 0;
@@ -898,11 +934,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
                                g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
-                               redo, f_out, write_f, pl.counters, kflags, sj);                               \
+                               redo, f_out, write_f, pl.counters, kflags, sj, pl.order);                     \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);              \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj, pl.order);    \
     }
             SBTV_FUSED_CASE(4, 8, 4)
 #ifdef SBTV_LAB
