@@ -517,7 +517,11 @@ __device__ __forceinline__ double2 spec_apply(double2 V, double2 H, double2 Y, d
     } else if constexpr (OP == OP_SALSA) {
         const double d = cabs2(H) + mu;
         const double2 num = cadd(cmulc(Y, H), cscale(V, mu));     // conj(H) Y + mu S
+#ifdef SBTV_SPEC_IEEE_DIV
         const double rd = 1.0 / d;                                // one IEEE reciprocal instead of two divisions
+#else
+        const double rd = fast_rcp(d);                            // d in [mu, 1 + mu]: rcp + one cubic step (~1 ulp)
+#endif
         const double2 Xh = make_double2(num.x * rd, num.y * rd);
         const double2 R = csub(Y, cmul(H, Xh));
         acc[0] += wgt * cabs2(R);

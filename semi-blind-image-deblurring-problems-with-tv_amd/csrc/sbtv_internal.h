@@ -182,6 +182,15 @@ int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int
 int stage_out_buf(sbtv_ctx *ctx, const char *name, double *p, size_t count, int flags, double **dev);
 int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count, int flags);
 
+// 1/d for a divisor of ordinary magnitude (the spectral solve: d = |H|^2 + mu in [mu, 1 + mu]): v_rcp_f64 and one cubic
+// correction r0 (1 + e + e^2), e = 1 - d r0, three FMAs, within ~1 ulp of the IEEE quotient (the IEEE division expands
+// to ~20 instructions with scaling steps that such divisors never need); the form validated in the fused Chambolle kernel
+__device__ __forceinline__ double fast_rcp(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+
 // ---- K9: Philox4x32-10 counter-based generator + Box-Muller -> standard normals.
 // counter = (pixel-pair index lo, hi, step, chain) ; key = seed.  One call yields 128 random bits =
 // two 53-bit uniforms = two normals = one double2 of Z.  (Statistical parity only: MATLAB's

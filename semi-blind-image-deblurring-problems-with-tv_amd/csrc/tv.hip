@@ -368,8 +368,18 @@ __device__ __forceinline__ void fused_tl(int slot) {
     }
 }
 #define SBTV_TL(slot) fused_tl(slot)
+// per-WAVE stamps of the shader-clock counter around the two barriers of every fused iteration, for every 16th workgroup:
+// slot 0 = entry of the step loop, then per step: before / after the first barrier, before / after the second one
+constexpr int TLW_SLOTS = 24, TLW_SAMPLES = 128, TLW_EVERY = 16;
+__device__ unsigned long long g_fused_tlw[TLW_SAMPLES * 16 * TLW_SLOTS];
+__device__ __forceinline__ void fused_tlw(int slot) {
+    if ((threadIdx.x & 63) != 0 || (blockIdx.x % TLW_EVERY) != 0 || blockIdx.x / TLW_EVERY >= TLW_SAMPLES || slot >= TLW_SLOTS) return;
+    g_fused_tlw[((size_t)(blockIdx.x / TLW_EVERY) * 16 + (threadIdx.x >> 6)) * TLW_SLOTS + slot] = __builtin_readcyclecounter();
+}
+#define SBTV_TLW(slot) fused_tlw(slot)
 #else
 #define SBTV_TL(slot)
+#define SBTV_TLW(slot)
 #endif
 #include "tv_fused.inc"
 #include "tv_fused1.inc"
@@ -1151,6 +1161,16 @@ extern "C" int sbtv_debug_timeline(sbtv_ctx *ctx, unsigned long long *out, int n
     if (!ctx || !out || nrec < 1 || nrec > 8192) return SBTV_ERR_BADARG;
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SBTV_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(sbtv::g_fused_tl), sizeof(unsigned long long) * 8 * (size_t)nrec));
+    return 0;
+}
+// per-wave barrier stamps of the last launch: out[TLW_SAMPLES][16 waves][TLW_SLOTS]
+extern "C" int sbtv_debug_timeline_waves(sbtv_ctx *ctx, unsigned long long *out, int *samples, int *every, int *slots) {
+    if (!ctx || !out) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SBTV_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(sbtv::g_fused_tlw), sizeof(sbtv::g_fused_tlw)));
+    if (samples) *samples = sbtv::TLW_SAMPLES;
+    if (every) *every = sbtv::TLW_EVERY;
+    if (slots) *slots = sbtv::TLW_SLOTS;
     return 0;
 }
 #endif

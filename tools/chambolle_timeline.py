@@ -77,6 +77,41 @@ for off in range(8):
     if m > 0.5 and off: print(f"| … equals (workgroup id + {off}) mod 8 | {100 * m:.1f} % |")
 print(f"| distinct XCC_IDs seen | {len(np.unique(xcc))} |")
 
+# ---- per-wave stamps around the two barriers of every fused iteration (every 16th workgroup, shader-clock counter)
+wave = None
+try:
+    ctx.lib.sbtv_debug_timeline_waves.restype = C.c_int
+    ctx.lib.sbtv_debug_timeline_waves.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    ns_, ev_, sl_ = C.c_int(0), C.c_int(0), C.c_int(0)
+    raw = np.zeros(128 * 16 * 24, dtype=np.uint64)
+    assert ctx.lib.sbtv_debug_timeline_waves(ctx.h, raw.ctypes.data_as(C.c_void_p), C.byref(ns_), C.byref(ev_), C.byref(sl_)) == 0
+    tw = raw.reshape(ns_.value, 16, sl_.value)[:min(ns_.value, (ntile + ev_.value - 1) // ev_.value), :8, :21].astype(np.int64)
+    ok = np.all(tw[:, :, 0] > 0, axis=1)
+    tw = tw[ok]
+    # per step: compute A = (after barrier 2 of the previous step | loop entry) -> before barrier 1 ; wait 1 ; compute B =
+    # after barrier 1 -> before barrier 2 ; wait 2
+    a = np.stack([tw[:, :, 1 + 4 * s] - (tw[:, :, 0] if s == 0 else tw[:, :, 4 * s]) for s in range(5)], axis=2)
+    w1 = np.stack([tw[:, :, 2 + 4 * s] - tw[:, :, 1 + 4 * s] for s in range(5)], axis=2)
+    b_ = np.stack([tw[:, :, 3 + 4 * s] - tw[:, :, 2 + 4 * s] for s in range(5)], axis=2)
+    w2 = np.stack([tw[:, :, 4 + 4 * s] - tw[:, :, 3 + 4 * s] for s in range(5)], axis=2)
+    tot = (tw[:, :, 20] - tw[:, :, 0]).astype(float)
+    wave = dict(n=int(tw.shape[0]), a=a, w1=w1, b=b_, w2=w2, tot=tot)
+    print("\n## Inside the five iterations: every wave's time between and AT the two barriers (shader-clock ticks)\n")
+    print(f"{tw.shape[0]} sampled workgroups x 8 waves.  A = exchange phase (read the seam column of py, form u of the first column, write it: "
+          "up to barrier 1); B = the four columns (up to barrier 2).\n")
+    print("| wave | total ticks (5 its) | in A | waiting at barrier 1 | in B | waiting at barrier 2 |\n|---|---|---|---|---|---|")
+    for wv in range(8):
+        t = tot[:, wv].mean()
+        print(f"| {wv} | {t:.0f} | {100 * a[:, wv].sum(axis=1).mean() / t:.1f} % | {100 * w1[:, wv].sum(axis=1).mean() / t:.1f} % | "
+              f"{100 * b_[:, wv].sum(axis=1).mean() / t:.1f} % | {100 * w2[:, wv].sum(axis=1).mean() / t:.1f} % |")
+    t = tot.mean()
+    print(f"| all | {t:.0f} | {100 * a.sum(axis=2).mean() / t:.1f} % | {100 * w1.sum(axis=2).mean() / t:.1f} % | "
+          f"{100 * b_.sum(axis=2).mean() / t:.1f} % | {100 * w2.sum(axis=2).mean() / t:.1f} % |")
+    print(f"\nB per step and wave: median {np.median(b_):.0f} ticks (10 % {np.percentile(b_, 10):.0f}, 90 % {np.percentile(b_, 90):.0f}); "
+          f"A: median {np.median(a):.0f}; barrier-1 wait median {np.median(w1):.0f}, barrier-2 wait median {np.median(w2):.0f}.")
+except Exception as e:      # an older debug library without the per-wave stamps
+    print(f"\n(per-wave stamps not available: {e})")
+
 # machine-readable summary for bench.py's roofline block (tail_frac), stamped with the kernel sources it was measured on
 if os.environ.get("TIMELINE_JSON"):
     import json
@@ -85,6 +120,11 @@ if os.environ.get("TIMELINE_JSON"):
                "workgroup_life_us_median": float(np.median(life)), "load_wait_us_median": float(np.median(load)),
                "iterate_us_median": float(np.median(comp)), "store_issue_us_median": float(np.median(store)),
                "cu_two_workgroups_iterating_frac": float(busy[2]), "cu_no_workgroup_iterating_frac": float(busy[0]),
+               "wave_phase_fracs": None if wave is None else {
+                   "exchange_phase": float(wave["a"].sum(axis=2).mean() / wave["tot"].mean()),
+                   "wait_barrier1": float(wave["w1"].sum(axis=2).mean() / wave["tot"].mean()),
+                   "column_phase": float(wave["b"].sum(axis=2).mean() / wave["tot"].mean()),
+                   "wait_barrier2": float(wave["w2"].sum(axis=2).mean() / wave["tot"].mean())},
                "how": "tools/chambolle_timeline.py on `make timeline` (clock stamps by thread 0 of every workgroup), last "
                       "launch of a 40-iteration SALSA solve at 2048^2"},
               open(os.environ["TIMELINE_JSON"], "w"), indent=1)
