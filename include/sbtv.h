@@ -211,7 +211,8 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
  *      'MAXITERA',n,'CONTINUATIONFACTOR',delta,'EPSILON',eps,...)   (SALSA/CSALSA_v2.m:160-561)
  * with invLS(r,mu) = real(ifft2(fft2(r)./(|H|^2+mu))) (:116 of its help, called as invLS(r,mu1) :471).
  * opts: stopcriterion 1..3 (default of the reference: 3), maxiter, TViters, initialization, tolA and the
- * Chambolle knobs are used; `speculate` is ignored.  Traces are 1-based like the reference: entry 0 is the
+ * Chambolle knobs are used; `speculate` as for sbtv_SALSA_v2 (bit 0: the host evaluates the stop rule one iteration late,
+ * bit 1: never launch the TV prox optimistically); a continuation factor != 1 selects exact launches and no lag.  Traces are 1-based like the reference: entry 0 is the
  * state before the loop, the loop runs outer = 2..maxiter (:461).  All trace rows have maxiter entries.
  * epsilon[b] = 0 selects sqrt(numel(y)+8*sqrt(numel(y)))*sigma[b] (:413).  n_outer[b] = last `outer`. */
 int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch,

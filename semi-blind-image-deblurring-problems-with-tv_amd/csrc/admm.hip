@@ -2,9 +2,13 @@
 // the same device kernels as SALSA_v2:
 //   C-SALSA  (SALSA/CSALSA_v2.m:160-561)  min TV(x)  s.t. ||Ax - y|| <= epsilon
 //   CoRAL    (SALSA/CoRAL_v2.m:2-476)     min 0.5||Ax-y||^2 + tau1 TV(x) + tau2 TV(x)   (two split copies)
-// Neither is called by the reference's demos, so they are written for clarity rather than fused to the
-// last pass: per outer iteration the host reads back a handful of scalars and applies the stop rule
-// (no speculation), and the images of a batch are solved one after another.
+// Neither is called by the reference's demos, so they are not fused to the last pass; what they share with the SALSA
+// loop since round 3 is its stream discipline: the Chambolle launches of an outer iteration are OPTIMISTIC (all TViters
+// iterations back to back, no stop-rule kernels, no redo pass; the host applies chambolle_prox_TV_stop.m:131 to the step
+// sums it reads with the iteration's scalars and, should the rule ever fire before the last step, repeats the solve with
+// exact launches: SBTV_ADMM_EXACT=1 forces those), and the host evaluates the outer stop rule one iteration late while
+// the next iteration already runs (x is double-buffered, so the result of the stopping iteration is intact).  The
+// images of a batch are solved one after another.
 #include <chrono>
 #include <cmath>
 
@@ -254,11 +258,50 @@ int check_common(sbtv_ctx *ctx, const char *who, const double *y, const double *
     return 0;
 }
 
+constexpr int ADMM_RESTART_EXACT = 12345;      // internal status: the optimistic prox met its stop rule early
+
+inline bool admm_exact_forced() {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_ADMM_EXACT");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
+// One warm-started TV prox of an outer iteration.  Optimistic: `nlaunch` counts the optimistic launches made on this plan
+// so far (the kernels read dual buffer cur ^ parity); the step sums of the K iterations go to stepsums[0..K).
+inline int admm_prox(sbtv_ctx *ctx, const ProxPlan &pp, const double *g, int K, double *f, bool spec, long long *nlaunch,
+                     double *stepsums, const double *lam_dev, double tol, double tau) {
+    if (!spec) {
+        SBTV_TRY(prox_reset(ctx, pp, lam_dev, 1.0, K, tol, tau, true, nullptr));
+        return prox_iterate(ctx, pp, g, K, f);
+    }
+    SBTV_TRY(prox_iterate(ctx, pp, g, K, f, false, 1, (int)(*nlaunch & 1), nullptr));
+    *nlaunch += prox_launches(pp, K);
+    return reduce_partials(ctx, pp.partials, K, pp.fnblk, stepsums);
+}
+// cont = (k < MaxIter) & (err > tol) over the K step sums: did the rule stop before the last step?
+inline bool admm_fired_early(const double *stepsums, int K, double tol) {
+    for (int k = 1; k < K; ++k)
+        if (!(sqrt(stepsums[k - 1]) > tol)) return true;
+    return false;
+}
+
+// Per-iteration scalars travel through two pinned slots; an event per slot tells the host (which runs one iteration
+// ahead) when slot `outer & 1` holds the scalars of iteration `outer`.
+struct AdmmSlots {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~AdmmSlots() {
+        for (auto e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps, int taille, double mu1, double mu2,
                double sigma, double epsilon, double delta, const sbtv_salsa_opts *opts, const double *td,
                const double *xi, double *x_out_dev, double *objective, double *distance1, double *distance2,
-               double *criterion, double *times, double *mses, int *numA, int *numAt, int *n_outer) {
+               double *criterion, double *times, double *mses, int *numA, int *numAt, int *n_outer, bool spec_wanted) {
     AdmmCommon c;
     SBTV_TRY(admm_common(ctx, M, N, taps, taille, nullptr, &c));
     ProxPlan pp;
@@ -279,12 +322,12 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
     SBTV_TRY(ws_get_t(ctx, "admm.g", P, &g));
     SBTV_TRY(ws_get_t(ctx, "admm.par", (size_t)4, &par));               // mu1, mu2, 1/mu1
     SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
-    SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)16, &sums));            // [0..5] update sums, [6] TV(x), [8] n_ve^2
+    SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)64, &sums));            // [0..5] update sums, [6] TV(x), [8] n_ve^2, [16..] prox step sums
     SBTV_TRY(ws_get_t(ctx, "admm.W", c.fp.u_img, &Ws));
     double *hs = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(double) * 16, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * 128, &pz));
         hs = static_cast<double *>(pz);
     }
     const int maxiter = opts->maxiter;
@@ -339,10 +382,19 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
     double crit_prev = sqrt(hs[0]), obj_prev = hs[6];
     const auto t0 = std::chrono::steady_clock::now();
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    int last = 1;
-    long long prox_iters = 0;
-    for (int outer = 2; outer <= maxiter; ++outer) {                     // :461
-        last = outer;
+    // optimistic prox launches need a fixed threshold (the control block is armed once) and the tile kernels
+    const int K = opts->TViters;
+    const bool spec = spec_wanted && delta == 1.0 && !(opts->speculate & 2) && !admm_exact_forced() && prox_spec_ok(pp, g, u, K);
+    const int lag = (spec && (opts->speculate & 1)) ? 1 : 0;
+    long long nlaunch = 0, prox_iters = 0;
+    AdmmSlots slots;
+    for (auto &e : slots.ev) SBTV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double *hslot[2] = {hs, hs + 64};
+    const bool tv_fused = fft_cols_tv_ok(c.fp);
+    const int ntv = tv_fused ? fft_cols_blocks(c.fp) : 0;
+    double *tvp = nullptr;
+    if (tv_fused) SBTV_TRY(ws_get_t(ctx, "admm.tvc", (size_t)ntv, &tvp));
+    auto enqueue = [&](int outer) -> int {                               // :461
         const int k = outer - 1;
         double *xn = xbuf[k & 1];
         const double *xprev = xbuf[(k & 1) ^ 1];
@@ -370,32 +422,55 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
             SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
             SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
         }
-        h_numAt += 1;
         // u = prox_{TV/mu1}(x - bu), warm-started duals (:476)
         hipLaunchKernelGGL(ad_sub_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, bu, g, P);
-        SBTV_TRY(prox_reset(ctx, pp, par + 2, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
-        SBTV_TRY(prox_iterate(ctx, pp, g, opts->TViters, u));
-        // Ax, projection on the epsilon ball, multipliers, traces (:481-501)
-        SBTV_TRY(admm_apply(ctx, c, OP_MUL_H, xn, Ax));
-        h_numA += 1;
-        ctx->calls += 3;                                                 // AT, invLS, A
+        SBTV_TRY(admm_prox(ctx, pp, g, K, u, spec, &nlaunch, sums + 16, par + 2, opts->chambolle_tol, opts->chambolle_tau));
+        // Ax (the forward column pass of x also leaves the periodic-TV partials of phi(x) = TVnorm(x), :498), projection on
+        // the epsilon ball, multipliers, traces (:481-501)
+        {
+            RowsArgs a{};
+            a.dir_fwd = 1;
+            a.dir_inv = 1;
+            a.op = OP_MUL_H;
+            a.H = c.Hs;
+            SBTV_TRY(fft_cols_fwd_f(ctx, c.fp, xn, nullptr, c.S, nullptr, tvp));
+            SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
+            SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, Ax, c.inv_scale));
+        }
         hipLaunchKernelGGL(csalsa_ve_kernel, dim3(nb), dim3(AB), 0, ctx->stream, Ax, yd, bv, partials, P);
         SBTV_TRY(reduce_partials(ctx, partials, 1, nb, sums + 8));
         hipLaunchKernelGGL(csalsa_update_kernel, dim3(nb), dim3(AB), 0, ctx->stream, Ax, yd, xn, u, v, bv, bu, td,
                            (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, sums + 8, epsilon, partials, P);
         SBTV_TRY(reduce_partials(ctx, partials, 6, nb, sums));
-        SBTV_TRY(tvnorm_dev(ctx, xn, M, N, 1, sums + 6));
+        if (tv_fused) SBTV_TRY(reduce_partials(ctx, tvp, 1, ntv, sums + 6));
+        else SBTV_TRY(tvnorm_dev(ctx, xn, M, N, 1, sums + 6));
         SBTV_HIP(ctx, hipGetLastError());
-        SBTV_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipMemcpyAsync(hs + 8, pp.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        prox_iters += *reinterpret_cast<const int *>(hs + 8);
-        const double crit = sqrt(hs[0]), obj = hs[6];
+        double *hsl = hslot[outer & 1];
+        SBTV_HIP(ctx, hipMemcpyAsync(hsl, sums, sizeof(double) * (16 + (spec ? K : 0)), hipMemcpyDeviceToHost, ctx->stream));
+        if (!spec) SBTV_HIP(ctx, hipMemcpyAsync(hsl + 8, pp.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipEventRecord(slots.ev[outer & 1], ctx->stream));
+        return 0;
+    };
+    bool stop = false, fired = false;
+    // host side of iteration `outer`: traces (:494-501) and the stop rule (:517-541)
+    auto process = [&](int outer) -> int {
+        const int k = outer - 1;
+        const double *hsl = hslot[outer & 1];
+        SBTV_HIP(ctx, hipEventSynchronize(slots.ev[outer & 1]));
+        if (spec && admm_fired_early(hsl + 16, K, opts->chambolle_tol)) {
+            fired = true;
+            return 0;
+        }
+        prox_iters += spec ? K : *reinterpret_cast<const int *>(hsl + 8);
+        h_numAt += 1;
+        h_numA += 1;
+        ctx->calls += 3;                                                 // AT, invLS, A
+        const double crit = sqrt(hsl[0]), obj = hsl[6];
         if (criterion) criterion[k] = crit;                              // :494
-        if (distance1) distance1[k] = sqrt(hs[1]);                       // :495
-        if (distance2) distance2[k] = sqrt(hs[2]);                       // :497
+        if (distance1) distance1[k] = sqrt(hsl[1]);                      // :495
+        if (distance2) distance2[k] = sqrt(hsl[2]);                      // :497
         if (objective) objective[k] = obj;                               // :498
-        if (mses && td) mses[k] = hs[3] / (double)P;                     // :501
+        if (mses && td) mses[k] = hsl[3] / (double)P;                    // :501
         if (times) times[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (delta != 1.0) {                                              // :517-518
             mu1 *= delta;
@@ -406,12 +481,23 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
         if (opts->stopcriterion == 1)
             sc = fabs(obj - obj_prev) / obj;                             // :527
         else if (opts->stopcriterion == 2)
-            sc = fabs(sqrt(hs[4]) / sqrt(hs[5]));                        // :534
+            sc = fabs(sqrt(hsl[4]) / sqrt(hsl[5]));                      // :534
         else
             sc = fabs(crit - crit_prev) / crit;                          // :539
         obj_prev = obj;
         crit_prev = crit;
-        if (sc < opts->tolA && crit <= epsilon) break;                   // :529,535,541
+        stop = (sc < opts->tolA && crit <= epsilon);                     // :529,535,541
+        return 0;
+    };
+    int last = 1, enq = 1, done = 1;
+    while (!stop && done < maxiter) {
+        while (enq < maxiter && enq - done <= lag) SBTV_TRY(enqueue(++enq));
+        SBTV_TRY(process(++done));
+        if (fired) {
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return ADMM_RESTART_EXACT;
+        }
+        last = done;
     }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -435,7 +521,7 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
 int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps, int taille, double tau1, double tau2,
               double mu1, double mu2, double mu_ls, int TViters2, const sbtv_salsa_opts *opts, const double *td,
               const double *xi, double *x_out_dev, double *objective, double *distance, double *times, double *mses,
-              int *numA, int *numAt, int *n_outer) {
+              int *numA, int *numAt, int *n_outer, bool spec_wanted) {
     AdmmCommon c;
     SBTV_TRY(admm_common(ctx, M, N, taps, taille, yd, &c));
     ProxPlan pu, pv;
@@ -455,12 +541,12 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
     SBTV_TRY(ws_get_t(ctx, "admm.g2", P, &g2));
     SBTV_TRY(ws_get_t(ctx, "admm.par", (size_t)4, &par));               // mu_ls, thr1, thr2
     SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
-    SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)16, &sums));            // [0..6] post sums, [8] resid2, [9] TV(u), [10] TV(v)
+    SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)96, &sums));            // [0..6] post sums, [8] resid2, [9] TV(u), [10] TV(v), [16..], [48..] step sums
     SBTV_TRY(ws_get_t(ctx, "admm.acc", (size_t)3 * nrb, &acc));
     double *hs = nullptr;
     {
         void *pz = nullptr;
-        SBTV_TRY(pinned_get(ctx, sizeof(double) * 16, &pz));
+        SBTV_TRY(pinned_get(ctx, sizeof(double) * 192, &pz));
         hs = static_cast<double *>(pz);
     }
     {
@@ -516,19 +602,26 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
     double obj_prev = hs[15];
     const auto t0 = std::chrono::steady_clock::now();
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    int last = 0;
-    long long prox_iters = 0;
-    for (int outer = 1; outer <= maxiter; ++outer) {                     // :394
-        last = outer;
+    const int K1 = opts->TViters, K2 = TViters2;
+    const bool spec = spec_wanted && !(opts->speculate & 2) && !admm_exact_forced() && prox_spec_ok(pu, g1, u, K1) &&
+                      prox_spec_ok(pv, g2, v, K2);
+    const int lag = (spec && (opts->speculate & 1)) ? 1 : 0;
+    long long nl_u = 0, nl_v = 0, prox_iters = 0;
+    AdmmSlots slots;
+    for (auto &e : slots.ev) SBTV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    double *hslot[2] = {hs, hs + 96};
+    auto enqueue = [&](int outer) -> int {                               // :394
         double *xn = xbuf[outer & 1];
         const double *xprev = xbuf[(outer & 1) ^ 1];
-        // the two TV proxes with their own warm-started duals (:401,406)
-        if (outer > 1) {
-            SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
-            SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, TViters2, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+        // the two TV proxes with their own warm-started duals (:401,406).  The first outer iteration always runs exactly:
+        // its prox inputs x - bu = x - bv are zero and the rule stops at k = 1; its control blocks are re-armed afterwards
+        const bool sp = spec && outer >= 2;
+        if (spec && outer == 2) {
+            SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, K1, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+            SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, K2, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
         }
-        SBTV_TRY(prox_iterate(ctx, pu, g1, opts->TViters, u));
-        SBTV_TRY(prox_iterate(ctx, pv, g2, TViters2, v));
+        SBTV_TRY(admm_prox(ctx, pu, g1, K1, u, sp, &nl_u, sums + 16, par + 1, opts->chambolle_tol, opts->chambolle_tau));
+        SBTV_TRY(admm_prox(ctx, pv, g2, K2, v, sp, &nl_v, sums + 48, par + 2, opts->chambolle_tol, opts->chambolle_tau));
         // r = ATy + mu1 (u+bu) + mu2 (v+bv) ; x = invLS(r)   (:411-413)  + residual energy (:423, Parseval)
         hipLaunchKernelGGL(coral_s_kernel, dim3(nb), dim3(AB), 0, ctx->stream, u, bu, v, bv, mu1, mu2, mu_ls, s, P);
         {
@@ -544,8 +637,6 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
             SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
             SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
         }
-        h_numA += 1;
-        ctx->calls += 2;                                                 // invLS, A
         hipLaunchKernelGGL(coral_post_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn,
                            (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, u, v, bu, bv, g1, g2, td, partials, P);
         SBTV_TRY(reduce_partials(ctx, partials, 7, nb, sums));
@@ -553,32 +644,58 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
         SBTV_TRY(tvnorm_dev(ctx, u, M, N, 1, sums + 9));
         SBTV_TRY(tvnorm_dev(ctx, v, M, N, 1, sums + 10));
         SBTV_HIP(ctx, hipGetLastError());
-        SBTV_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipMemcpyAsync(hs + 12, pu.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipMemcpyAsync(hs + 13, pv.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        prox_iters += *reinterpret_cast<const int *>(hs + 12) + *reinterpret_cast<const int *>(hs + 13);
-        const double f = 0.5 * (hs[8] * c.parseval) + tau1 * hs[9] + tau2 * hs[10];      // :425
+        double *hsl = hslot[outer & 1];
+        SBTV_HIP(ctx, hipMemcpyAsync(hsl, sums, sizeof(double) * (sp ? 80 : 12), hipMemcpyDeviceToHost, ctx->stream));
+        if (!sp) {
+            SBTV_HIP(ctx, hipMemcpyAsync(hsl + 12, pu.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SBTV_HIP(ctx, hipMemcpyAsync(hsl + 13, pv.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        SBTV_HIP(ctx, hipEventRecord(slots.ev[outer & 1], ctx->stream));
+        return 0;
+    };
+    bool stop = false, fired = false;
+    auto process = [&](int outer) -> int {
+        const double *hsl = hslot[outer & 1];
+        const bool sp = spec && outer >= 2;
+        SBTV_HIP(ctx, hipEventSynchronize(slots.ev[outer & 1]));
+        if (sp && (admm_fired_early(hsl + 16, K1, opts->chambolle_tol) || admm_fired_early(hsl + 48, K2, opts->chambolle_tol))) {
+            fired = true;
+            return 0;
+        }
+        prox_iters += sp ? (long long)(K1 + K2)
+                         : (long long)(*reinterpret_cast<const int *>(hsl + 12) + *reinterpret_cast<const int *>(hsl + 13));
+        h_numA += 1;
+        ctx->calls += 2;                                                 // invLS, A
+        const double f = 0.5 * (hsl[8] * c.parseval) + tau1 * hsl[9] + tau2 * hsl[10];      // :425
         if (objective) objective[outer] = f;
-        if (mses && td) mses[outer] = hs[0] / (double)P;                 // :428-429
+        if (mses && td) mses[outer] = hsl[0] / (double)P;                // :428-429
         if (distance) {
-            distance[(size_t)(outer - 1) * 2] = sqrt(hs[1]) / sqrt(hs[3] + hs[4]);       // :432
-            distance[(size_t)(outer - 1) * 2 + 1] = sqrt(hs[2]) / sqrt(hs[3] + hs[5]);   // :433
+            distance[(size_t)(outer - 1) * 2] = sqrt(hsl[1]) / sqrt(hsl[3] + hsl[4]);       // :432
+            distance[(size_t)(outer - 1) * 2 + 1] = sqrt(hsl[2]) / sqrt(hsl[3] + hsl[5]);   // :433
         }
         if (times) times[outer] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        bool stop = false;
         if (outer > 1) {                                                 // :435
             double crit;
             if (opts->stopcriterion == 1)
                 crit = fabs(f - obj_prev) / obj_prev;                    // :441
             else if (opts->stopcriterion == 2)
-                crit = fabs(sqrt(hs[6]) / sqrt(hs[3]));                  // :445
+                crit = fabs(sqrt(hsl[6]) / sqrt(hsl[3]));                // :445
             else
                 crit = f;                                                // :448
             stop = crit < opts->tolA;                                    // :453
         }
         obj_prev = f;
-        if (stop) break;
+        return 0;
+    };
+    int last = 0, enq = 0, done = 0;
+    while (!stop && done < maxiter) {
+        while (enq < maxiter && enq - done <= lag) SBTV_TRY(enqueue(++enq));
+        SBTV_TRY(process(++done));
+        if (fired) {
+            SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return ADMM_RESTART_EXACT;
+        }
+        last = done;
     }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -628,12 +745,22 @@ int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, cons
     const int mi = opts->maxiter;
     for (int b = 0; b < batch; ++b) {
         const size_t o = (size_t)b * P, r = (size_t)b * mi;
-        SBTV_TRY(csalsa_one(ctx, yd + o, M, N, taps + (size_t)b * taille * taille, taille, mu1[b], mu2[b], sigma[b],
-                            epsilon ? epsilon[b] : 0.0, continuationfactor, opts, td ? td + o : nullptr,
-                            xi ? xi + o : nullptr, xo + o, objective ? objective + r : nullptr,
-                            distance1 ? distance1 + r : nullptr, distance2 ? distance2 + r : nullptr,
-                            criterion ? criterion + r : nullptr, times ? times + r : nullptr, mses ? mses + r : nullptr,
-                            numA ? numA + b : nullptr, numAt ? numAt + b : nullptr, n_outer ? n_outer + b : nullptr));
+        const long long calls0 = ctx->calls;
+        for (int attempt = 0; attempt < 2; ++attempt) {       // optimistic prox launches first; exact ones if the rule fired early
+            const int rc = csalsa_one(ctx, yd + o, M, N, taps + (size_t)b * taille * taille, taille, mu1[b], mu2[b], sigma[b],
+                                      epsilon ? epsilon[b] : 0.0, continuationfactor, opts, td ? td + o : nullptr,
+                                      xi ? xi + o : nullptr, xo + o, objective ? objective + r : nullptr,
+                                      distance1 ? distance1 + r : nullptr, distance2 ? distance2 + r : nullptr,
+                                      criterion ? criterion + r : nullptr, times ? times + r : nullptr,
+                                      mses ? mses + r : nullptr, numA ? numA + b : nullptr, numAt ? numAt + b : nullptr,
+                                      n_outer ? n_outer + b : nullptr, attempt == 0);
+            if (rc == ADMM_RESTART_EXACT && attempt == 0) {
+                ctx->calls = calls0;
+                continue;
+            }
+            SBTV_TRY(rc);
+            break;
+        }
     }
     SBTV_TRY(stage_out_copy(ctx, x_out, xo, cnt, flags));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -664,12 +791,22 @@ int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     const int mi = opts->maxiter;
     for (int b = 0; b < batch; ++b) {
         const size_t o = (size_t)b * P;
-        SBTV_TRY(coral_one(ctx, yd + o, M, N, taps + (size_t)b * taille * taille, taille, tau1[b], tau2[b], mu1[b], mu2[b],
-                           mu_ls ? mu_ls[b] : mu1[b] + mu2[b], TViters2, opts, td ? td + o : nullptr,
-                           xi ? xi + o : nullptr, xo + o, objective ? objective + (size_t)b * (mi + 1) : nullptr,
-                           distance ? distance + (size_t)b * mi * 2 : nullptr, times ? times + (size_t)b * (mi + 1) : nullptr,
-                           mses ? mses + (size_t)b * (mi + 1) : nullptr, numA ? numA + b : nullptr,
-                           numAt ? numAt + b : nullptr, n_outer ? n_outer + b : nullptr));
+        const long long calls0 = ctx->calls;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int rc = coral_one(ctx, yd + o, M, N, taps + (size_t)b * taille * taille, taille, tau1[b], tau2[b], mu1[b],
+                                     mu2[b], mu_ls ? mu_ls[b] : mu1[b] + mu2[b], TViters2, opts, td ? td + o : nullptr,
+                                     xi ? xi + o : nullptr, xo + o, objective ? objective + (size_t)b * (mi + 1) : nullptr,
+                                     distance ? distance + (size_t)b * mi * 2 : nullptr,
+                                     times ? times + (size_t)b * (mi + 1) : nullptr,
+                                     mses ? mses + (size_t)b * (mi + 1) : nullptr, numA ? numA + b : nullptr,
+                                     numAt ? numAt + b : nullptr, n_outer ? n_outer + b : nullptr, attempt == 0);
+            if (rc == ADMM_RESTART_EXACT && attempt == 0) {
+                ctx->calls = calls0;
+                continue;
+            }
+            SBTV_TRY(rc);
+            break;
+        }
     }
     SBTV_TRY(stage_out_copy(ctx, x_out, xo, cnt, flags));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
