@@ -97,8 +97,9 @@ try:
     tot = (tw[:, :, 20] - tw[:, :, 0]).astype(float)
     wave = dict(n=int(tw.shape[0]), a=a, w1=w1, b=b_, w2=w2, tot=tot)
     print("\n## Inside the five iterations: every wave's time between and AT the two barriers (shader-clock ticks)\n")
-    print(f"{tw.shape[0]} sampled workgroups x 8 waves.  A = exchange phase (read the seam column of py, form u of the first column, write it: "
-          "up to barrier 1); B = the four columns (up to barrier 2).\n")
+    print(f"{tw.shape[0]} sampled workgroups x 8 waves.  A = from barrier 2 to barrier 1 (split schedule: columns 2..0 + u of column 0 of "
+          "the next step; first schedule: only the exchange of the seam column); B = from barrier 1 to barrier 2 (split schedule: "
+          "the last column; first schedule: all four columns).\n")
     print("| wave | total ticks (5 its) | in A | waiting at barrier 1 | in B | waiting at barrier 2 |\n|---|---|---|---|---|---|")
     for wv in range(8):
         t = tot[:, wv].mean()
