@@ -487,7 +487,11 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     // Optimistic prox launches (no stop-rule kernels, no redo pass: 6 launches less per iteration); the host applies the
     // rule over the prox_iters step sums when it reads the iteration's scalars and, should it have stopped early, repeats
     // the whole call with exact launches (flag SBTV_FISTA_EXACT_PROX), so the result is always that of the exact rule.
-    const bool prox_spec = !(flags & SBTV_FISTA_EXACT_PROX) && prox_spec_ok(pp, y, x, prox_iters);
+    // (not when a device-resident x_out overlaps an input: frozen images are copied into x_out while the loop runs, and a
+    // repeated call would then start from damaged inputs - such a call takes the exact launches from the start)
+    auto overlaps_out = [&](const double *p) { return p && x_out && (p < x_out + cnt) && (x_out < p + cnt); };
+    const bool out_aliases_input = (flags & SBTV_DEVICE_PTRS) && (overlaps_out(bimg) || overlaps_out(true_x));
+    const bool prox_spec = !(flags & SBTV_FISTA_EXACT_PROX) && !out_aliases_input && prox_spec_ok(pp, y, x, prox_iters);
     bool prox_was_spec = false;
     // objective / sums of iterate `xk` of iteration k -> pinned slot k & 1, tagged with k
     auto objective_of_x = [&](const double *xk, int k, const int *frozen, const double *mom_partials) -> int {
