@@ -394,6 +394,31 @@ def extra_configs(ctx, dev, iters):
         e = time.perf_counter() - t1
         return e
 
+    # several devices behind ONE process through the C-ABI (sbtv_group): on this one-GPU run two VIRTUAL shards on the same
+    # device (two host threads, two contexts), 4 images of the headline problem dealt 2 + 2, host (NumPy) buffers as a MATLAB
+    # host would pass them - what the group path costs and gains when it has no second GPU to use
+    try:
+        x1, y1, s1, _ = make_problem(seed=1)
+        g = sbtv.Group([ctx.device, ctx.device])
+        Ag = sbtv.BlurOperator(sbtv.Gaussian_psf(7, *W_TRUE), ctx=ctx)
+        mu_g, tau_g = THETA / 10, THETA * s1 ** 2
+        ys, xs = np.stack([y1] * 4), np.stack([x1] * 4)
+        run = lambda n: sbtv.SALSA_v2(ys, Ag, tau_g, "MU", mu_g, "AT", Ag.T, "LS", Ag.LS(mu_g), "True_x", xs, "StopCriterion", 1,
+                                      "ToleranceA", -1.0, "MAXITERA", n, "TVINITIALIZATION", 1, "TViters", 10, ctx=g)
+        run(5)
+        ng = max(iters, 200)             # long enough for the host <-> device copies of the 4 images (~25 ms) to be a side note
+        t1 = time.perf_counter()
+        run(ng)
+        eg = time.perf_counter() - t1
+        g.close()
+        out["group_2_virtual_shards_4x2048"] = {
+            "workload": "sbtv_SALSA_v2_sharded: 4 images of the headline problem over a group of two contexts on THIS GPU "
+                        "(virtual shards), host buffers in and out (PCIe copies of 3 x 32 MiB per image are inside the time)",
+            "value": 4 * ng / eg, "unit": "image-iterations/s", "steps": ng, "ms_per_iteration": 1e3 * eg / ng}
+        del ys, xs
+    except Exception as e:               # the group path must not take the headline line down with it
+        out["group_2_virtual_shards_4x2048"] = {"error": str(e)}
+
     e = sapg("laplace", 1024, 8, False)
     out["sapg_laplace_8x1024"] = {"workload": "SAPG_algorithm_laplace, chambolleit 25, 8 independent 1024x1024 images in one "
                                               "call = one GPU's share of the 64 of configs[3], device Philox noise",
