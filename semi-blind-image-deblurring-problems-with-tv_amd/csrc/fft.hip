@@ -1035,10 +1035,14 @@ int fft_cols_inv(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, 
 int fft_cols_blocks(const FftPlan &pl) { return (pl.wave || pl.generic) ? pl.N : pl.N / cols_nseq(pl); }
 int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
                       const ColsPost &post) {
+    if ((!pl.wave && (post.bu_in || post.skip_x)) || (post.bu_in && !post.skip_x))
+        return fail(ctx, SBTV_ERR_BADARG, "fft_cols_inv_post: bu_in + skip_x go together and need the wave-granular column pass");
     if (pl.generic) return any_cols_inv(ctx, pl, S, x, scale, frozen, &post);
     if (pl.wave) {
         const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
-        const int pm = 1 + (post.tru ? 2 : 0) + (post.xprev ? 4 : 0);
+        if (post.skip_x && (!post.bu_in || post.bu_in == post.bu || post.xprev))
+            return fail(ctx, SBTV_ERR_BADARG, "fft_cols_inv_post: skip_x needs a separate bu_in and no xprev");
+        const int pm = 1 + (post.tru ? 2 : 0) + (post.xprev ? 4 : 0) + (post.skip_x ? 32 : 0);
 #define SBTV_POST_CASE(PM_)                                                                                          \
     case PM_:                                                                                                        \
         if (pl.n1 == 1024)                                                                                           \
@@ -1053,6 +1057,8 @@ int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double
             SBTV_POST_CASE(3)
             SBTV_POST_CASE(5)
             SBTV_POST_CASE(7)
+            SBTV_POST_CASE(33)
+            SBTV_POST_CASE(35)
         }
 #undef SBTV_POST_CASE
         SBTV_HIP(ctx, hipGetLastError());

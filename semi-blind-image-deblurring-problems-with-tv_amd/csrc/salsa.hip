@@ -13,6 +13,7 @@
 // Speculative pipelining: the host enqueues outer iteration k+1 before it has seen the scalars of
 // iteration k, so the GPU never waits for the stop-rule round trip.  x is double-buffered, hence
 // when iteration k turns out to be the last one its x is still intact (one wasted iteration).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 
@@ -27,6 +28,16 @@ namespace sbtv {
 __global__ void prox_park_kernel(ProxCtrl *__restrict__ ctrl, const int *__restrict__ frozen, int batch) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < batch && frozen[b]) ctrl[b].done = 1;
+}
+
+// x = g + bu = (x - bu) + bu of an image's last iteration (NOX mode of sbtv_SALSA_v2: x is not stored in the loop)
+__global__ __launch_bounds__(256) void salsa_recover_x_kernel(const double *__restrict__ g, const double *__restrict__ bu,
+                                                               double *__restrict__ x, size_t P) {
+#pragma clang fp contract(off)
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < P / 2; q += (size_t)gridDim.x * 256) {
+        const double2 a = *reinterpret_cast<const double2 *>(g + 2 * q), b = *reinterpret_cast<const double2 *>(bu + 2 * q);
+        *reinterpret_cast<double2 *>(x + 2 * q) = make_double2(a.x + b.x, a.y + b.y);
+    }
 }
 
 // grid (7 [+ psteps], batch): see collect.inc (salsa_collect_block); the same blocks can ride on the first Chambolle
@@ -102,11 +113,28 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     // before, after that write).  Not when x_out overlaps an input (an optimistic solve that has to be repeated reads
     // them again) and not with captured iterations (their arguments are frozen).
     auto overlaps_out = [&](const double *p) { return p && x_out && (p < x_out + cnt) && (x_out < p + cnt); };
-    const bool direct_last = x_out && (flags & SBTV_DEVICE_PTRS) && !graph_wanted(cnt) && !overlaps_out(yd) &&
-                             !overlaps_out(td) && !overlaps_out(xi);
+    const bool direct_last_ok = x_out && (flags & SBTV_DEVICE_PTRS) && !graph_wanted(cnt) && !overlaps_out(yd) &&
+                                !overlaps_out(td) && !overlaps_out(xi);
     SBTV_TRY(ws_get_t(ctx, "salsa.u", cnt, &u));
     SBTV_TRY(ws_get_t(ctx, "salsa.bu", cnt, &bu));
     SBTV_TRY(ws_get_t(ctx, "salsa.g", cnt, &g));
+    // NOX (sizes of the wave-granular column pass, stop criteria 1 and 3, eager launches): the inverse column pass does not
+    // STORE x (one of the eight array passes of the bookkeeping kernel: -2.5 % of an outer iteration at 2048^2).  Nothing in
+    // the loop reads x again; the final x of an image is recovered as g + bu = (x - bu) + bu of ITS last iteration, so g
+    // and bu alternate between two buffers by iteration parity (the host learns one iteration late which one was the
+    // last; x was double-buffered for the same reason).  The recovered x differs from the transform's output by the
+    // rounding of that sum (<= 1 ulp of |x| + |bu|, ~3e-14 on 0..255 data).  SBTV_SALSA_NOX=0: store x.
+    static const bool env_nox = [] {
+        const char *e = getenv("SBTV_SALSA_NOX");
+        return !(e && e[0] == '0');
+    }();
+    const bool nox = env_nox && fft_cols_inv_step_ok(fp) && !crit2 && !graph_wanted(cnt) && x_out != nullptr;
+    double *gb[2] = {g, g}, *bub[2] = {bu, bu};
+    if (nox) {
+        SBTV_TRY(ws_get_t(ctx, "salsa.bu1", cnt, &bub[1]));
+        SBTV_TRY(ws_get_t(ctx, "salsa.g1", cnt, &gb[1]));
+    }
+    const bool direct_last = direct_last_ok && !nox;
     double2 *S = nullptr, *Hs = nullptr, *Ys = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.S", (size_t)batch * fp.s_img, &S));
     SBTV_TRY(ws_get_t(ctx, "salsa.H", (size_t)batch * fp.u_img, &Hs));
@@ -383,7 +411,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         // in place (u = 0, duals = 0) and no launch is needed; the host books the one iteration.
         // (the duals are never cleared: the first prox that is launched starts cold)
         if (!(zero_start && outer == 1))
-            SBTV_TRY(prox_iterate(ctx, pps, g, opts->TViters, u, outer == (zero_start ? 2 : 1), spec,
+            SBTV_TRY(prox_iterate(ctx, pps, gb[(outer - 1) & 1], opts->TViters, u, outer == (zero_start ? 2 : 1), spec,
                                   spec ? ((outer - 2) * nl_prox) & 1 : 0, side.nblocks ? &side : nullptr));
         if (timed) SBTV_HIP(ctx, hipEventRecord(ev_p1[slot], ctx->stream));
         prox_timed[slot] = timed;
@@ -397,14 +425,18 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         a.mu = mu_d;
         a.acc = acc;
         a.frozen = frozen_d;
-        SBTV_TRY(fft_cols_fwd_f(ctx, fp, u, bu, S, frozen_d));
+        SBTV_TRY(fft_cols_fwd_f(ctx, fp, u, bub[(outer - 1) & 1], S, frozen_d));
         SBTV_TRY(fft_rows(ctx, fp, S, S, a));
         // (3) inverse column pass fused with the bu update, the next prox input and the sums
         //     incl. TVnorm(u) (:440-451), while x is still in registers
         ColsPost cp;
         cp.u = u;
-        cp.bu = bu;
-        cp.g = g;
+        cp.bu = bub[outer & 1];
+        cp.g = gb[outer & 1];
+        if (nox) {
+            cp.bu_in = bub[(outer - 1) & 1];
+            cp.skip_x = 1;
+        }
         cp.tru = td;
         cp.xprev = crit2 ? xprev : nullptr;
         cp.partials = postp;
@@ -611,7 +643,26 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         ctx->hstat.majflt = (double)(ru1.ru_majflt - ru0.ru_majflt);
     }
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if (x_out) {
+    if (x_out && nox) {
+        // image b's result is g + bu of ITS last processed iteration (x itself was never stored)
+        for (int b = 0; b < batch; ++b) {
+            const int par = h_nouter[b] & 1;
+            const bool dev_direct = direct_last_ok;      // device-resident x_out that overlaps no input
+            double *dst = dev_direct ? x_out + (size_t)b * P : xbuf[0] + (size_t)b * P;
+            const int nblk = (int)std::min<size_t>((P / 2 + 255) / 256, 2048);
+            if (h_nouter[b] == 0) {          // no iteration ran (maxiter = 0): the start image
+                SBTV_HIP(ctx, hipMemcpyAsync(dst, x + (size_t)b * P, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+            } else {
+                hipLaunchKernelGGL(salsa_recover_x_kernel, dim3(nblk), dim3(256), 0, ctx->stream,
+                                   (const double *)(gb[par] + (size_t)b * P), (const double *)(bub[par] + (size_t)b * P), dst, P);
+                SBTV_HIP(ctx, hipGetLastError());
+            }
+            if (!dev_direct)
+                SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, dst, sizeof(double) * P,
+                                             (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                             ctx->stream));
+        }
+    } else if (x_out) {
         // image b's result is the x written by ITS last processed iteration
         for (int b = 0; b < batch; ++b) {
             if (direct_last && h_nouter[b] == maxiter) continue;        // already there

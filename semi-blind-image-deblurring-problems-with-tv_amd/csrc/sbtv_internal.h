@@ -365,6 +365,11 @@ struct ColsPost {
     const double *u = nullptr;
     double *bu = nullptr;
     double *g = nullptr;
+    // wave-granular kernel only (sizes of fft_cols_inv_step_ok): bu is READ from bu_in (null: from `bu`, in place) and
+    // written to `bu`; skip_x: the transform's output x is used for the bookkeeping but not stored (the SALSA loop can
+    // recover its final x as g + bu, see salsa.hip)
+    const double *bu_in = nullptr;
+    int skip_x = 0;
     const double *tru = nullptr;
     const double *xprev = nullptr;
     double *partials = nullptr;      // [batch][6][fft_cols_blocks]

@@ -68,9 +68,12 @@ def _salsa(ctx, fx, tag, pr):
     x2, _, _, obj2, _, _, _ = solve(n_outer, -1.0)
     assert len(obj2) - 1 == n_outer
     np.testing.assert_array_equal(obj2, obj)
-    np.testing.assert_array_equal(sbtv.to_host(x2), xh)
+    np.testing.assert_array_equal(sbtv.to_host(x2), xh)        # the same bits whether the solve ended by tolerance or by MAXITERA
     _check_crops(fx, f"{tag}.u", ctx.workspace("salsa.u", M, N))
-    _check_crops(fx, f"{tag}.bu", ctx.workspace("salsa.bu", M, N))
+    # on the sizes of the wave-granular column pass bu (and g) alternate between two buffers by iteration parity (the loop
+    # does not store x there and recovers the final x as g + bu, csrc/salsa.hip)
+    two_buffers = M in (1024, 2048) and N in (1024, 2048) and os.environ.get("SBTV_SALSA_NOX", "1") != "0"
+    _check_crops(fx, f"{tag}.bu", ctx.workspace("salsa.bu1" if (two_buffers and n_outer % 2) else "salsa.bu", M, N))
     return psnr
 
 
