@@ -156,9 +156,10 @@ def model_step_bytes(size):
     """Minimum HBM bytes of one outer iteration of the fused design: 2 Chambolle launches (read g,px,py + write px,py;
     the second also writes u: 40 + 48 B/px), forward column FFT of u+bu (read 2, write S: 24), row pass (S in and out
     + the H and Y spectra of (M/2+1) x N complex each), inverse column FFT + bookkeeping (read S,u,bu,true; write
-    x,bu,g: 56)."""
+    x,bu,g: 56; at 1024 / 2048 x is not stored since round 3: 48)."""
     n1 = size // 2
-    return (40.0 + 48.0 + 24.0 + (16.0 + 16.0 * (n1 + 1) / n1) + 56.0) * float(size * size)
+    post = 48.0 if size in (1024, 2048) else 56.0
+    return (40.0 + 48.0 + 24.0 + (16.0 + 16.0 * (n1 + 1) / n1) + post) * float(size * size)
 
 
 def pass_block(ctx, size, names, reps):
@@ -406,15 +407,23 @@ def extra_configs(ctx, dev, iters):
         run = lambda n: sbtv.SALSA_v2(ys, Ag, tau_g, "MU", mu_g, "AT", Ag.T, "LS", Ag.LS(mu_g), "True_x", xs, "StopCriterion", 1,
                                       "ToleranceA", -1.0, "MAXITERA", n, "TVINITIALIZATION", 1, "TViters", 10, ctx=g)
         run(5)
-        ng = max(iters, 200)             # long enough for the host <-> device copies of the 4 images (~25 ms) to be a side note
+        # two call lengths: the slope is the loop, the intercept the fixed part of a call - for this PYTHON host mostly the
+        # row-major -> column-major conversion of the NumPy images (a MATLAB host's arrays are column-major already) plus
+        # the host <-> device copies (tools/bench_group.py: ~340 ms for the 4 images, single context or group alike)
+        n_a, n_b = 50, 250
         t1 = time.perf_counter()
-        run(ng)
-        eg = time.perf_counter() - t1
+        run(n_a)
+        t2 = time.perf_counter()
+        run(n_b)
+        t3 = time.perf_counter()
         g.close()
+        slope = ((t3 - t2) - (t2 - t1)) / (n_b - n_a)
         out["group_2_virtual_shards_4x2048"] = {
             "workload": "sbtv_SALSA_v2_sharded: 4 images of the headline problem over a group of two contexts on THIS GPU "
-                        "(virtual shards), host buffers in and out (PCIe copies of 3 x 32 MiB per image are inside the time)",
-            "value": 4 * ng / eg, "unit": "image-iterations/s", "steps": ng, "ms_per_iteration": 1e3 * eg / ng}
+                        "(virtual shards: two host threads, no second device to gain from), host buffers in and out",
+            "value": 4.0 / slope, "unit": "image-iterations/s", "value_is": "slope between calls of %d and %d outer iterations" % (n_a, n_b),
+            "ms_per_iteration": 1e3 * slope, "fixed_ms_per_call": 1e3 * ((t2 - t1) - n_a * slope),
+            "calls_ms": [1e3 * (t2 - t1), 1e3 * (t3 - t2)]}
         del ys, xs
     except Exception as e:               # the group path must not take the headline line down with it
         out["group_2_virtual_shards_4x2048"] = {"error": str(e)}
