@@ -340,3 +340,30 @@ def test_salsa_stop_rule_firing_inside_the_prox_restarts_exactly(ctx):
     # the prox did stop early in the exact run: fewer Chambolle iterations than 6 x 10
     import sbtv._lib as L
     assert L.default_context().last_timing()["chambolle_launches"] < 6 * 10
+
+
+def test_salsa_1024_batch_images_stop_at_different_iterations_equal_their_single_solves(ctx, man512):
+    """1024 x 1024 is a size of the wave-granular column pass: the loop does not store x there, g and bu alternate between
+    two buffers by iteration parity and an image's result is recovered as g + bu of ITS last iteration (csrc/salsa.hip).
+    Two images that stop at different outer iterations (one at an odd, one at an even one when the tolerances allow) in one
+    call must each equal their own single-image solve bit for bit, and the oracle within the usual bars."""
+    import sbtv
+    import sbtv_oracle as o
+    xs = [np.tile(man512, (2, 2)), np.clip(np.tile(man512[::-1], (2, 2)) * 0.6 + 40, 0, 255)]
+    sts = [_problem(xs[b], seed=3 + b, BSNR=30.0 if b == 0 else 22.0) for b in range(2)]
+    theta = 0.03
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    mu = theta / 10
+    taus = [theta * st["sigma"] ** 2 for st in sts]
+    args = ("MU", mu, "AT", A.T, "LS", A.LS(mu), "ToleranceA", 2e-4, "MAXITERA", 80, "TVINITIALIZATION", 1, "TViters", 10)
+    both = sbtv.SALSA_v2(np.stack([st["y"] for st in sts]), A, taus, *args, "True_x", np.stack(xs))
+    n = [len(both[3][b]) - 1 for b in range(2)]
+    assert n[0] != n[1] and max(n) < 80, n
+    for b in range(2):
+        one = sbtv.SALSA_v2(sts[b]["y"], A, taus[b], *args, "True_x", xs[b])
+        np.testing.assert_array_equal(both[0][b], one[0])
+        np.testing.assert_array_equal(both[3][b], one[3])
+        ref = o.salsa_from_estimates(sts[b], theta, sts[b]["p_true"], sts[b]["sigma"] ** 2, tol=2e-4, outeriters=80)
+        assert ref["n_outer"] == n[b]
+        np.testing.assert_allclose(one[3], ref["objective"], rtol=1e-9)
+        assert np.max(np.abs(one[0] - ref["x"])) < 1e-6
