@@ -549,7 +549,7 @@ __device__ __forceinline__ double2 spec_apply(double2 V, double2 H, double2 Y, d
 // TILED: S is in the tiled layout (a workgroup's RK rows x 4 columns are then 64 RK contiguous bytes) and the operator
 // spectra are row-major U[k][l] (fft_wave.inc); otherwise S[l][k] and U[l][k].
 template <int LOG2N, int RK, int OP, bool TILED = false>
-__global__ __launch_bounds__(RK *((1 << LOG2N) / 8)) void fft_rows_kernel(RowsParams p) {
+__global__ __launch_bounds__(RK *((1 << LOG2N) / 8), (TILED && RK == 2) ? 4 : 1) void fft_rows_kernel(RowsParams p) {
     constexpr int N = 1 << LOG2N, T = N / 8;
     constexpr int LDSI = RK * N;
     constexpr int LDSN = LDSI + ((LDSI >> 5) << 2) + 8;
@@ -837,11 +837,24 @@ static inline bool rows_pipe(int log2n) {
 #ifdef SBTV_LAB
     static const bool on = [] {
         const char *e = getenv("SBTV_ROWS_PIPE");
-        return !(e && e[0] == '0');
+        return !(e && (e[0] == '0' || e[0] == '2'));
     }();
     return on;
 #else
     return true;
+#endif
+}
+// lab: SBTV_ROWS_PIPE=2 = the workgroup row kernel with TWO rows per 512-thread workgroup on the tiled layout (74 KB of LDS,
+// no operand prefetch: two workgroups fit a CU) - round 3's "two independent workgroups per CU" experiment
+static inline int rows_wg_rk() {
+#ifdef SBTV_LAB
+    static const int rk = [] {
+        const char *e = getenv("SBTV_ROWS_PIPE");
+        return (e && e[0] == '2') ? 2 : 4;
+    }();
+    return rk;
+#else
+    return 4;
 #endif
 }
 #ifdef SBTV_LAB
@@ -1094,7 +1107,7 @@ static inline int rows_rk(const FftPlan &pl) {
 }
 int fft_rows_blocks(const FftPlan &pl) {
     if (pl.generic) return ANY_SPEC_BLOCKS;
-    if (pl.wave) return rows_wave() ? pl.n1 / 2 : pl.n1 / 4;
+    if (pl.wave) return rows_wave() ? pl.n1 / 2 : (rows_pipe(0) ? pl.n1 / 4 : pl.n1 / rows_wg_rk());
     return pl.n1 / rows_rk(pl);
 }
 
@@ -1190,7 +1203,10 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
         }
 #ifdef SBTV_LAB
         // the workgroup row kernel on the tiled layout: 4 rows x 4 columns = 256 contiguous bytes per access
-        if (L == 11) launch_rows<11, 4, true>(ctx, pl, p);
+        if (rows_wg_rk() == 2) {
+            if (L == 11) launch_rows<11, 2, true>(ctx, pl, p);
+            else launch_rows<10, 2, true>(ctx, pl, p);
+        } else if (L == 11) launch_rows<11, 4, true>(ctx, pl, p);
         else launch_rows<10, 4, true>(ctx, pl, p);
         SBTV_HIP(ctx, hipGetLastError());
         return 0;

@@ -53,6 +53,10 @@ mu, tau = bench.THETA / 10, bench.THETA * sigma ** 2
 def solve(n):
     return sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0, "MAXITERA", n,
                          "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+# the converged solve of the bench problem against its committed oracle fixture (stopping iteration, PSNR)
+xg, _, _, obj, _, _, _ = sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", 1e-5, "MAXITERA", 500,
+                                      "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+res["salsa_fixture"] = bench.fixture_check("salsa2048", bench.psnr(x, sbtv.to_host(xg)), len(obj) - 1)["matches"]
 solve(300)
 vals = []
 for rep in range(3):
@@ -90,6 +94,7 @@ def main():
             d["variant"] = lib
             print(json.dumps(d), file=sys.stderr, flush=True)
             rows.append(d)
+    print("(every run: converged 2048² solve vs its oracle fixture: " + ", ".join(str(d.get("salsa_fixture")) for d in rows) + ")\n")
     print("| library | SALSA it/s @2048² | µs / Chambolle it (loop) | launch of 1 / 3 / 5 its (µs) | prox10 warm / prox25 cold (µs) | "
           "parity vs oracle: max abs px, f; rel err |")
     print("|---|---|---|---|---|---|")
