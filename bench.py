@@ -669,7 +669,10 @@ def main():
         if batched:
             line["batched"] = batched
         if extras and not args.no_extra_configs:
-            line["extra_configs"] = extra_configs(ctx, dev, args.extra_iters)
+            try:
+                line["extra_configs"] = extra_configs(ctx, dev, args.extra_iters)
+            except Exception as e:           # an auxiliary block must not take the headline line down with it
+                line["extra_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(x, noise, args.cpu_budget)
         print(json.dumps(line), flush=True)
