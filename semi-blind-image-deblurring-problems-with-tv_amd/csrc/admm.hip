@@ -125,6 +125,61 @@ __global__ __launch_bounds__(AB) void csalsa_update_kernel(const double *__restr
     ad_store_partials<6>(acc, partials);
 }
 
+// ---- C-SALSA with the constraint split kept as a spectrum (default; see csalsa_one) ------------------------------
+// After the row pass: the three spectral sums of the iteration -> the projection factor s = min(1, eps / ||ve||), the
+// coefficients of the next row pass and the two traces that depend on Ax.  st: [0] mu2, [1] c_e = mu2 (2s-1),
+// [2] c_keep = 1-s, [3] sum |E|^2 of the previous iteration (unscaled), [4] 1 - s of the previous iteration.
+//   out[0] = ||Ax-y||^2, out[1] = ||Ax-y-v||^2 = ||(1-s) E' - (1-s_prev) E||^2 from |E'|^2, |E|^2 and |E'-E|^2:
+//   (a-c)(a A1 - c A1p) + a c A2 (no difference of large numbers once the iteration settles: a -> c, E' -> E)
+__global__ void csalsa_scal_kernel(const double *__restrict__ rs, double *__restrict__ st, double eps, double pv,
+                                   double *__restrict__ out) {
+    const double A0 = rs[0], A1 = rs[1], A2 = rs[2];
+    const double n_ve = sqrt(A1 * pv);
+    const double sfac = (n_ve <= eps) ? 1.0 : eps / n_ve;
+    const double a = 1.0 - sfac, c = st[4], A1p = st[3];
+    const double d1 = ((a - c) * (a * A1 - c * A1p) + a * c * A2) * pv;
+    out[0] = A0 * pv;
+    out[1] = d1 > 0.0 ? d1 : 0.0;
+    st[1] = st[0] * (2.0 * sfac - 1.0);
+    st[2] = a;
+    st[3] = A1;
+    st[4] = a;
+}
+
+// after the prox: bu <- bu - (x - u) (:492) and the sums of the traces that live in the image domain
+//   partials [5][nb]: (x-u)^2, (x-true)^2, (x-xprev)^2, x^2, periodic TV(x) (utils/TVnorm.m:2)
+__global__ __launch_bounds__(AB) void csalsa_post_kernel(const double *__restrict__ x, const double *__restrict__ u,
+                                                          double *__restrict__ bu, const double *__restrict__ tru,
+                                                          const double *__restrict__ xprev, double *__restrict__ partials,
+                                                          unsigned M, unsigned N, size_t P) {
+    double acc[5] = {0, 0, 0, 0, 0};
+    AD_LOOP(q, P) {
+        const double2 xv = AD_LD(x, q), uv = AD_LD(u, q), bb = AD_LD(bu, q);
+        const double d0 = xv.x - uv.x, d1 = xv.y - uv.y;
+        AD_ST(bu, q, make_double2(bb.x - d0, bb.y - d1));
+        acc[0] += d0 * d0 + d1 * d1;
+        if (tru) {
+            const double2 tv = AD_LD(tru, q);
+            const double m0 = xv.x - tv.x, m1 = xv.y - tv.y;
+            acc[1] += m0 * m0 + m1 * m1;
+        }
+        if (xprev) {
+            const double2 xo = AD_LD(xprev, q);
+            const double m0 = xv.x - xo.x, m1 = xv.y - xo.y;
+            acc[2] += m0 * m0 + m1 * m1;
+        }
+        acc[3] += xv.x * xv.x + xv.y * xv.y;
+        // element 2q = (i, j), i even (M is even on this path): left neighbours in column j-1, upper neighbour of row i
+        const unsigned idx = (unsigned)(2 * q), j = idx / M, i = idx - j * M;
+        const size_t lcol = (size_t)(j > 0 ? j - 1 : N - 1) * M + i;
+        const double2 xl = *reinterpret_cast<const double2 *>(x + lcol);
+        const double xu = x[(size_t)j * M + (i > 0 ? i - 1 : M - 1)];
+        const double h0 = xv.x - xl.x, v0 = xv.x - xu, h1 = xv.y - xl.y, v1 = xv.y - xv.x;
+        acc[4] += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
+    }
+    ad_store_partials<5>(acc, partials);
+}
+
 // ---- CoRAL -------------------------------------------------------------------------------------
 // s = (mu1 (u+bu) + mu2 (v+bv)) / mu_ls                                     (CoRAL_v2.m:411, ATy enters spectrally)
 __global__ __launch_bounds__(AB) void coral_s_kernel(const double *__restrict__ u, const double *__restrict__ bu,
@@ -194,6 +249,7 @@ struct AdmmCommon {
     double2 *S, *Hs, *Ys;
     double *taps_d;
     double inv_scale, parseval;
+    bool spectral = false;
 };
 
 int admm_common(sbtv_ctx *ctx, int M, int N, const double *taps, int taille, const double *yd, AdmmCommon *c) {
@@ -268,6 +324,15 @@ inline bool admm_exact_forced() {
     return on;
 }
 
+// C-SALSA: the constraint split (v, bv) as ONE spectrum and a scalar (default) or as images (SBTV_CSALSA_SPECTRAL=0)
+inline bool csalsa_spectral_wanted() {
+    static const bool on = [] {
+        const char *e = getenv("SBTV_CSALSA_SPECTRAL");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // One warm-started TV prox of an outer iteration.  Optimistic: `nlaunch` counts the optimistic launches made on this plan
 // so far (the kernels read dual buffer cur ^ parity); the step sums of the K iterations go to stepsums[0..K).
 inline int admm_prox(sbtv_ctx *ctx, const ProxPlan &pp, const double *g, int K, double *f, bool spec, long long *nlaunch,
@@ -303,7 +368,17 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
                const double *xi, double *x_out_dev, double *objective, double *distance1, double *distance2,
                double *criterion, double *times, double *mses, int *numA, int *numAt, int *n_outer, bool spec_wanted) {
     AdmmCommon c;
-    SBTV_TRY(admm_common(ctx, M, N, taps, taille, nullptr, &c));
+    {
+        FftPlan chk;
+        SBTV_TRY(fft_plan(ctx, M, N, 1, &chk));
+        // spectral form of the constraint split (see `enqueue_spectral` below): needs fixed mu1 / mu2, an even M (pairs of
+        // one column per lane) and the row kernels that carry OP_CSALSA
+        const bool sp = delta == 1.0 && !admm_exact_forced() && csalsa_spectral_wanted() && fft_rows_csalsa_ok(chk) && !(M & 1) &&
+                        (size_t)M * N < ((size_t)1 << 31);
+        SBTV_TRY(admm_common(ctx, M, N, taps, taille, sp ? yd : nullptr, &c));
+        c.spectral = sp;
+    }
+    const bool spectral = c.spectral;
     ProxPlan pp;
     SBTV_TRY(prox_plan(ctx, M, N, 1, &pp));
     const size_t P = c.P;
@@ -324,6 +399,10 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
     SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
     SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)64, &sums));            // [0..5] update sums, [6] TV(x), [8] n_ve^2, [16..] prox step sums
     SBTV_TRY(ws_get_t(ctx, "admm.W", c.fp.u_img, &Ws));
+    double2 *Es = Ws;                                                   // spectral form: the state spectrum E (W is not formed)
+    double *cst = nullptr, *rs = nullptr;
+    SBTV_TRY(ws_get_t(ctx, "admm.cs", (size_t)8, &cst));
+    SBTV_TRY(ws_get_t(ctx, "admm.rs", (size_t)4, &rs));
     double *hs = nullptr;
     {
         void *pz = nullptr;
@@ -394,7 +473,53 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
     const int ntv = tv_fused ? fft_cols_blocks(c.fp) : 0;
     double *tvp = nullptr;
     if (tv_fused) SBTV_TRY(ws_get_t(ctx, "admm.tvc", (size_t)ntv, &tvp));
+    if (spectral) {
+        // v = bv = 0 before the loop: E = 0, s_prev = 1
+        const double h[8] = {mu2, mu2, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        SBTV_HIP(ctx, hipMemsetAsync(Es, 0, sizeof(double2) * c.fp.u_img, ctx->stream));
+        SBTV_HIP(ctx, hipMemcpyAsync(cst, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // Spectral form of an outer iteration.  The projection on the epsilon ball scales ve = Ax - y - bv by ONE scalar
+    // s = min(1, eps/||ve||) (:485-489), so v = s ve, bv' = bv - (Ax - y - v) = -(1 - s) ve, and the next right-hand side
+    // y + v + bv' = y + (2s - 1) ve: the split (v, bv) is the spectrum E of ve and the scalar s.  One row pass then does
+    // what took three transforms: W = mu2 (Y + (2 s_prev - 1) E), X = (conj(H) W + mu1 S)/(|H|^2 + mu1), T = H X - Y
+    // (= fft2(Ax - y)), E' = T + (1 - s_prev) E, with ||Ax-y||^2, ||ve||^2 and ||E' - E||^2 by Parseval (the norms the
+    // traces and the next s need).  Image-domain work left: u + bu into the forward pass, x - bu for the prox, and one
+    // pass for bu, TV(x) and the sums over x.
+    auto enqueue_spectral = [&](int outer) -> int {
+        const int k = outer - 1;
+        double *xn = xbuf[k & 1];
+        const double *xprev = xbuf[(k & 1) ^ 1];
+        RowsArgs a{};
+        a.dir_fwd = 1;
+        a.dir_inv = 1;
+        a.op = OP_CSALSA;
+        a.H = c.Hs;
+        a.Y = c.Ys;
+        a.E = Es;
+        a.cs = cst;
+        a.mu = par;                                                      // mu1
+        a.acc = acc;
+        SBTV_TRY(fft_cols_fwd(ctx, c.fp, u, bu, c.S));
+        SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
+        SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
+        SBTV_TRY(reduce_partials(ctx, acc, 3, fft_rows_blocks(c.fp), rs));
+        hipLaunchKernelGGL(csalsa_scal_kernel, dim3(1), dim3(1), 0, ctx->stream, rs, cst, epsilon, c.parseval, sums);
+        hipLaunchKernelGGL(ad_sub_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, bu, g, P);
+        SBTV_TRY(admm_prox(ctx, pp, g, K, u, spec, &nlaunch, sums + 16, par + 2, opts->chambolle_tol, opts->chambolle_tau));
+        hipLaunchKernelGGL(csalsa_post_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, u, bu, td,
+                           (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, partials, (unsigned)M, (unsigned)N, P);
+        SBTV_TRY(reduce_partials(ctx, partials, 5, nb, sums + 2));
+        SBTV_HIP(ctx, hipGetLastError());
+        double *hsl = hslot[outer & 1];
+        SBTV_HIP(ctx, hipMemcpyAsync(hsl, sums, sizeof(double) * (16 + (spec ? K : 0)), hipMemcpyDeviceToHost, ctx->stream));
+        if (!spec) SBTV_HIP(ctx, hipMemcpyAsync(hsl + 8, pp.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SBTV_HIP(ctx, hipEventRecord(slots.ev[outer & 1], ctx->stream));
+        return 0;
+    };
     auto enqueue = [&](int outer) -> int {                               // :461
+        if (spectral) return enqueue_spectral(outer);
         const int k = outer - 1;
         double *xn = xbuf[k & 1];
         const double *xprev = xbuf[(k & 1) ^ 1];

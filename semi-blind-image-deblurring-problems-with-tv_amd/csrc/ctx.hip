@@ -382,6 +382,8 @@ int sbtv_ctx_destroy(sbtv_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->loop_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

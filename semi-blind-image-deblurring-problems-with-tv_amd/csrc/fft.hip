@@ -491,6 +491,8 @@ struct RowsParams {
     double2 *Sout;
     const double2 *tw;      // length N
     const double2 *H, *Y, *D1, *D2;
+    double2 *E;             // OP_CSALSA: state spectrum (layout of H), updated in place
+    const double *cs;       // OP_CSALSA: coefficients (device)
     const double *mu;
     double *acc;            // [batch][3][nrb]
     const int *frozen;
@@ -546,6 +548,30 @@ __device__ __forceinline__ double2 spec_apply(double2 V, double2 H, double2 Y, d
     }
 }
 
+// OP_CSALSA (see SpecOp): E is this element of the state spectrum, replaced by its new value
+struct CsPar {
+    double c_y, c_e, c_keep;
+};
+__device__ __forceinline__ double2 spec_apply_cs(double2 V, double2 H, double2 Y, double2 &E, double mu, const CsPar &c,
+                                                 double wgt, double (&acc)[3]) {
+    const double d = cabs2(H) + mu;
+    const double2 W = cadd(cscale(Y, c.c_y), cscale(E, c.c_e));
+    const double2 num = cadd(cmulc(W, H), cscale(V, mu));         // conj(H) W + mu S
+#ifdef SBTV_SPEC_IEEE_DIV
+    const double rd = 1.0 / d;
+#else
+    const double rd = fast_rcp(d);                                // d in [mu, 1 + mu]
+#endif
+    const double2 Xh = make_double2(num.x * rd, num.y * rd);
+    const double2 T = csub(cmul(H, Xh), Y);                       // spectrum of A x - y
+    const double2 En = cadd(T, cscale(E, c.c_keep));
+    acc[0] += wgt * cabs2(T);
+    acc[1] += wgt * cabs2(En);
+    acc[2] += wgt * cabs2(csub(En, E));
+    E = En;
+    return Xh;
+}
+
 // TILED: S is in the tiled layout (a workgroup's RK rows x 4 columns are then 64 RK contiguous bytes) and the operator
 // spectra are row-major U[k][l] (fft_wave.inc); otherwise S[l][k] and U[l][k].
 template <int LOG2N, int RK, int OP, bool TILED = false>
@@ -581,8 +607,9 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8), (TILED && RK == 2) ? 4 : 1)
     // bound by the chain of memory round trips, not by throughput: they request the operator spectra of their row
     // together with the row itself, BEFORE the forward transform (one round trip instead of nine: written as a loop
     // the compiler waits for every spectrum value separately).  The workgroup with the packed row 0 keeps the loop.
-    constexpr bool PRE = (OP != OP_NONE) && (RK * T <= 256);
-    constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF);
+    constexpr bool CS = (OP == OP_CSALSA);       // its own branch below (the state spectrum is read AND written)
+    constexpr bool PRE = (OP != OP_NONE) && !CS && (RK * T <= 256);
+    constexpr bool needY = (OP == OP_SALSA || OP == OP_RESID || OP == OP_GRAD || OP == OP_GRADF || CS);
     constexpr bool needD = (OP == OP_GRAD);
     const size_t hbase = p.shared_spec ? 0 : (size_t)b * p.u_img;
     double2 hh[PRE ? 8 : 1], yy[(PRE && needY) ? 8 : 1], dd1[(PRE && needD) ? 8 : 1], dd2[(PRE && needD) ? 8 : 1];
@@ -617,7 +644,51 @@ __global__ __launch_bounds__(RK *((1 << LOG2N) / 8), (TILED && RK == 2) ? 4 : 1)
     double acc[3] = {0.0, 0.0, 0.0};
     if constexpr (OP != OP_NONE) {
         const double mu = p.mu ? p.mu[b] : 0.0;
-        if (kb == 0) {
+        if constexpr (CS) {
+            const CsPar cp{p.cs[0], p.cs[1], p.cs[2]};
+            double2 *__restrict__ Ep = p.E + hbase;
+            const double2 *__restrict__ Hp = p.H + hbase, *__restrict__ Yp = p.Y + hbase;
+            if (kb == 0) {
+                double2 m[8];
+                mirror<LOG2N>(v, m, t, X);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int l = t + s * T;
+                    if (q == 0) {
+                        const size_t h0 = uidx(0, l), hn = uidx(n1, l);
+                        const double2 P = v[s], Q = cconj(m[s]);
+                        const double2 A = cscale(cadd(P, Q), 0.5);
+                        const double2 dB = csub(P, Q);
+                        const double2 B = make_double2(0.5 * dB.y, -0.5 * dB.x);   // (P-Q)/(2i)
+                        double2 e0 = Ep[h0], en = Ep[hn];
+                        const double2 A2 = spec_apply_cs(A, Hp[h0], Yp[h0], e0, mu, cp, 1.0, acc);
+                        const double2 B2 = spec_apply_cs(B, Hp[hn], Yp[hn], en, mu, cp, 1.0, acc);
+                        Ep[h0] = e0;
+                        Ep[hn] = en;
+                        v[s] = make_double2(A2.x - B2.y, A2.y + B2.x);             // A' + i B'
+                    } else {
+                        const size_t hk = uidx(k, l);
+                        double2 e = Ep[hk];
+                        v[s] = spec_apply_cs(v[s], Hp[hk], Yp[hk], e, mu, cp, 2.0, acc);
+                        Ep[hk] = e;
+                    }
+                }
+            } else {
+                double2 hh2[8], yy2[8], ee2[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const size_t hk = uidx(k, t + s * T);
+                    hh2[s] = Hp[hk];
+                    yy2[s] = Yp[hk];
+                    ee2[s] = Ep[hk];
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    v[s] = spec_apply_cs(v[s], hh2[s], yy2[s], ee2[s], mu, cp, 2.0, acc);
+                    Ep[uidx(k, t + s * T)] = ee2[s];
+                }
+            }
+        } else if (kb == 0) {
             // the block that owns the packed row 0 = X[0,:] + i X[M/2,:]
             double2 m[8];
             mirror<LOG2N>(v, m, t, X);
@@ -1105,6 +1176,13 @@ static inline int rows_rk(const FftPlan &pl) {
     const int small = (N == 512) ? 1 : (N == 256) ? 2 : rk;
     return (pl.n1 / rk < 128) ? small : rk;
 }
+bool fft_rows_csalsa_ok(const FftPlan &pl) {
+    if (pl.generic) return false;
+#ifdef SBTV_LAB
+    if (pl.wave && rows_wave()) return false;   // the lab's wave-granular row kernel does not carry it
+#endif
+    return true;
+}
 int fft_rows_blocks(const FftPlan &pl) {
     if (pl.generic) return ANY_SPEC_BLOCKS;
     if (pl.wave) return rows_wave() ? pl.n1 / 2 : (rows_pipe(0) ? pl.n1 / 4 : pl.n1 / rows_wg_rk());
@@ -1145,6 +1223,7 @@ static void launch_rows_pipe(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams 
         SBTV_ROWS_OP(OP_GRAD)
         SBTV_ROWS_OP(OP_ATA)
         SBTV_ROWS_OP(OP_GRADF)
+        SBTV_ROWS_OP(OP_CSALSA)
         default: break;
     }
 #undef SBTV_ROWS_OP
@@ -1165,6 +1244,7 @@ static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
         SBTV_ROWS_OP(OP_GRAD)
         SBTV_ROWS_OP(OP_ATA)
         SBTV_ROWS_OP(OP_GRADF)
+        SBTV_ROWS_OP(OP_CSALSA)
         default: break;
     }
 #undef SBTV_ROWS_OP
@@ -1179,6 +1259,8 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.Y = a.Y;
     p.D1 = a.D1;
     p.D2 = a.D2;
+    p.E = a.E;
+    p.cs = a.cs;
     p.mu = a.mu;
     p.acc = a.acc;
     p.frozen = a.frozen;
@@ -1190,6 +1272,7 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.u_img = pl.u_img;
     p.u_ld = pl.u_ld;
     p.u_tiled = pl.u_tiled;
+    if (a.op == OP_CSALSA && !fft_rows_csalsa_ok(pl)) return fail(ctx, SBTV_ERR_SIZE, "row pass: OP_CSALSA is not built for this plan");
     if (pl.generic) return any_rows(ctx, pl, p, Sout);
     const int L = ilog2(pl.N);
     if (L > 12) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 4096");

@@ -30,6 +30,13 @@ __global__ void prox_park_kernel(ProxCtrl *__restrict__ ctrl, const int *__restr
     if (b < batch && frozen[b]) ctrl[b].done = 1;
 }
 
+// start of a call: per-image parameters from the pinned staging block into device memory, frozen flags cleared
+__global__ void salsa_setup_kernel(const double *__restrict__ src, double *__restrict__ par, int npar, int *__restrict__ frozen,
+                                   int batch) {
+    for (int i = threadIdx.x; i < npar; i += blockDim.x) par[i] = src[i];
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) frozen[b] = 0;
+}
+
 // x = g + bu = (x - bu) + bu of an image's last iteration (NOX mode of sbtv_SALSA_v2: x is not stored in the loop)
 __global__ __launch_bounds__(256) void salsa_recover_x_kernel(const double *__restrict__ g, const double *__restrict__ bu,
                                                                double *__restrict__ x, size_t P) {
@@ -146,7 +153,6 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     double *taps_d = par, *mu_d = par + (size_t)batch * taille * taille, *thr_d = mu_d + batch;
     int *frozen_d = nullptr;
     SBTV_TRY(ws_get_t(ctx, "salsa.frozen", (size_t)batch, &frozen_d));
-    SBTV_HIP(ctx, hipMemsetAsync(frozen_d, 0, sizeof(int) * batch, ctx->stream));
     const int nrb = fft_rows_blocks(fp);
     const int npb = fft_cols_blocks(fp);      // partial sums per image of the fused column/bookkeeping pass
     double *acc = nullptr, *postp = nullptr;
@@ -186,7 +192,11 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             par_stage[(size_t)batch * taille * taille + b] = mu[b];
             par_stage[(size_t)batch * taille * taille + batch + b] = tau[b] / mu[b];   // threshold = tau/mu (:394)
         }
-        SBTV_HIP(ctx, hipMemcpyAsync(par, par_stage, sizeof(double) * npar, hipMemcpyHostToDevice, ctx->stream));
+        // one small kernel reads them from the pinned block and clears the frozen flags (a memset and a copy are two blit
+        // launches with 10-20 us of idle stream around each)
+        const double *par_stage_hd = reinterpret_cast<const double *>(scal_hd) + (par_stage - reinterpret_cast<double *>(scal_h));
+        hipLaunchKernelGGL(salsa_setup_kernel, dim3(1), dim3(256), 0, ctx->stream, par_stage_hd, par, (int)npar, frozen_d, batch);
+        SBTV_HIP(ctx, hipGetLastError());
     }
 
     const double inv_scale = 1.0 / ((double)fp.n1 * N);
@@ -302,26 +312,20 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     int active = batch;
     double ms_prox = 0.0;
     long long prox_iters_run = 0;
-    // events and captured graphs of this call: released on EVERY return path
+    // captured graphs of this call: released on EVERY return path.  The six events of the loop belong to the context
+    // (created on first use: creating and destroying them cost every call ~20 us of host time before its first launch)
     struct LoopResources {
-        hipEvent_t done[2] = {nullptr, nullptr}, p0[2] = {nullptr, nullptr}, p1[2] = {nullptr, nullptr};
         hipGraphExec_t gexec[2] = {nullptr, nullptr};
         ~LoopResources() {
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 2; ++s)
                 if (gexec[s]) (void)hipGraphExecDestroy(gexec[s]);
-                if (done[s]) (void)hipEventDestroy(done[s]);
-                if (p0[s]) (void)hipEventDestroy(p0[s]);
-                if (p1[s]) (void)hipEventDestroy(p1[s]);
-            }
         }
     } res;
-    hipEvent_t(&ev_done)[2] = res.done, (&ev_p0)[2] = res.p0, (&ev_p1)[2] = res.p1;
+    for (auto &e : ctx->loop_ev)
+        if (!e) SBTV_HIP(ctx, hipEventCreate(&e));
+    hipEvent_t ev_done[2] = {ctx->loop_ev[0], ctx->loop_ev[1]}, ev_p0[2] = {ctx->loop_ev[2], ctx->loop_ev[3]},
+               ev_p1[2] = {ctx->loop_ev[4], ctx->loop_ev[5]};
     hipGraphExec_t(&gexec)[2] = res.gexec;
-    for (int s = 0; s < 2; ++s) {
-        SBTV_HIP(ctx, hipEventCreate(&ev_done[s]));
-        SBTV_HIP(ctx, hipEventCreate(&ev_p0[s]));
-        SBTV_HIP(ctx, hipEventCreate(&ev_p1[s]));
-    }
     const auto t0 = std::chrono::steady_clock::now();
 
     // enqueue the kernels of outer iteration `outer` (reads x = xbuf[(outer-1)&1] through g, writes

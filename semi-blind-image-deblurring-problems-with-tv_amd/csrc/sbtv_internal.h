@@ -129,6 +129,7 @@ struct sbtv_ctx {
     void *pinned = nullptr;                    // pinned host staging for scalar read-back
     size_t pinned_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t loop_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // events of the SALSA loop (created on first use)
     int cu_count = 256;
     // SBTV_CANARY=1 (read when the context is created): every workspace gets a guard band on both sides,
     // verified at the end of each C-ABI call (canary_epilogue)
@@ -340,6 +341,9 @@ enum SpecOp {
     OP_GRAD = 6,      // X = conj(H) (H X - Y) ; acc0 += w|HX-Y|^2 ; acc1/2 += w Re(D1/2 X conj(HX-Y))
     OP_ATA = 7,       // X *= |H|^2
     OP_GRADF = 8,     // X = conj(H) (H X - Y) ; acc0 += w|HX-Y|^2
+    OP_CSALSA = 9,    // C-SALSA with its constraint state kept as a spectrum E (admm.hip): W = cs[0] Y + cs[1] E;
+                      // X = (conj(H) W + mu S) / (|H|^2+mu); T = H X - Y; E' = T + cs[2] E (stored in place);
+                      // acc0 += w|T|^2; acc1 += w|E'|^2; acc2 += w|E' - E|^2
 };
 struct FftPlan {
     int M, N, batch;
@@ -406,6 +410,8 @@ struct RowsArgs {
     const double2 *H;       // (M/2+1) x N per image (unpacked rows 0..M/2)
     const double2 *Y;       // same layout (OP_SALSA / OP_RESID / OP_GRAD)
     const double2 *D1, *D2; // derivative spectra (OP_GRAD), may be null
+    double2 *E;             // OP_CSALSA: state spectrum, layout of H, read and written in place
+    const double *cs;       // OP_CSALSA: three coefficients (device), see SpecOp
     const double *mu;       // per image (device)
     double *acc;            // partial sums [batch][3][nblk_rows]
     const int *frozen;      // optional per-image flag: skip image when set
@@ -413,6 +419,7 @@ struct RowsArgs {
 };
 int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout, const RowsArgs &a);
 int fft_rows_blocks(const FftPlan &pl);   // number of row blocks per image (acc stride)
+bool fft_rows_csalsa_ok(const FftPlan &pl);   // OP_CSALSA exists in the row kernels this plan uses
 // unpack packed spectrum S -> full rows 0..M/2 layout ((M/2+1) x N)
 int spec_unpack(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double2 *U);
 // direct evaluation of the tap spectrum: U[(M/2+1) x N] per image from taps[batch][taille^2] (device)

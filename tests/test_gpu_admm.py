@@ -55,6 +55,78 @@ def test_csalsa_matches_oracle(ctx, stop, init, delta):
     assert times[0] == 0 and np.all(np.diff(times) >= 0)
 
 
+def test_csalsa_spectral_form_matches_oracle_at_the_pipelined_size(ctx, man512):
+    """1024 x 1024 runs the pipelined row kernel with OP_CSALSA (the constraint split as a spectrum, csrc/admm.hip); 20
+    iterations against the oracle's image-domain restatement, projection active (epsilon below ||Ax - y|| at the start)."""
+    import sbtv
+    import sbtv_oracle as o
+    x = np.tile(man512, (2, 2))
+    st = _setup(x, seed=5)
+    A, AT, invLS = _oracle_handles(st)
+    mu1, mu2, K = 0.4, 0.7, 20
+    ref = o.CSALSA_v2(st["y"], A, mu1, mu2, st["sigma"], AT=AT, invLS=invLS, true_x=x, stopcriterion=3, tolA=1e-9,
+                      maxiter=K, TViters=5, initialization=2)
+    op = sbtv.BlurOperator(sbtv.psf_family("gaussian", 7, st["p_true"])[0])
+    got = sbtv.csalsa(st["y"], op, mu1, mu2, st["sigma"], "AT", op.T, "LS", op.invLS, "TVINITIALIZATION", 1,
+                      "TVITERS", 5, "STOPCRITERION", 3, "TOLERANCEA", 1e-9, "MAXITERA", K, "TRUE_X", x,
+                      "INITIALIZATION", 2, "VERBOSE", 0)
+    xg, numA, numAt, objective, d1, d2, crit, times, mses = got
+    assert len(objective) == ref["n_outer"] == K
+    assert np.any(np.asarray(ref["criterion"]) > ref["epsilon"]) and np.any(np.asarray(ref["criterion"]) <= ref["epsilon"] * 1.2)
+    np.testing.assert_allclose(objective, ref["objective"], rtol=1e-9)
+    np.testing.assert_allclose(crit, ref["criterion"], rtol=1e-8)
+    np.testing.assert_allclose(d1, ref["distance1"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(d2, ref["distance2"], rtol=1e-8)
+    np.testing.assert_allclose(mses, ref["mses"], rtol=1e-9)
+    assert np.max(np.abs(xg - ref["x"])) < 1e-7
+
+
+CS_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "semi-blind-image-deblurring-problems-with-tv_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import sbtv
+from conftest import synth_image
+res = {}
+for tag, (M, N) in (("a", (2048, 2048)), ("b", (256, 192)), ("c", (100, 90))):
+    x = synth_image(M, N, 8)
+    st = sbtv.demo_setup("gaussian", x, np.random.default_rng(2).standard_normal(x.shape), evMax=1.0)
+    op = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    got = sbtv.csalsa(st["y"], op, 0.5, 0.5, st["sigma"], "AT", op.T, "LS", op.invLS, "TVINITIALIZATION", 1, "TVITERS", 10,
+                      "STOPCRITERION", 2, "TOLERANCEA", 1e-9, "MAXITERA", 15, "TRUE_X", x, "VERBOSE", 0)
+    for nm, v in zip(("x", "obj", "d1", "d2", "crit", "mses"), (got[0], got[3], got[4], got[5], got[6], got[8])):
+        res[tag + "_" + nm] = np.asarray(v)
+np.savez(sys.argv[1], **res)
+"""
+
+
+def test_csalsa_spectral_and_image_forms_agree(tmp_path):
+    """The default (spectral constraint split, one FFT triple per iteration) against SBTV_CSALSA_SPECTRAL=0 (v, bv, Ax as
+    images, three FFT triples) at 2048^2 (pipelined row kernel), 256 x 192 (workgroup row kernel) and 100 x 90 (chirp-z
+    path: both runs take the image form there)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(name, env):
+        out = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", CS_CHILD % {"root": root}, out], check=True, env=e, timeout=900)
+        return np.load(out)
+    a, b = run("spectral", {}), run("images", {"SBTV_CSALSA_SPECTRAL": "0"})
+    for key in a.files:
+        if key.endswith("_x"):
+            assert np.max(np.abs(a[key] - b[key])) < 1e-8, key
+        elif key.endswith("_d1"):
+            np.testing.assert_allclose(a[key], b[key], rtol=1e-6, atol=1e-9, err_msg=key)
+        else:
+            np.testing.assert_allclose(a[key], b[key], rtol=1e-9, err_msg=key)
+    np.testing.assert_array_equal(a["c_x"], b["c_x"])
+
+
 def test_csalsa_reaches_the_constraint_set(ctx, cman256):
     """Domain property at a larger size: the iterates approach ||Ax - y|| = epsilon and improve on y."""
     import sbtv
