@@ -131,9 +131,23 @@ __global__ __launch_bounds__(AB) void csalsa_update_kernel(const double *__restr
 // [2] c_keep = 1-s, [3] sum |E|^2 of the previous iteration (unscaled), [4] 1 - s of the previous iteration.
 //   out[0] = ||Ax-y||^2, out[1] = ||Ax-y-v||^2 = ||(1-s) E' - (1-s_prev) E||^2 from |E'|^2, |E|^2 and |E'-E|^2:
 //   (a-c)(a A1 - c A1p) + a c A2 (no difference of large numbers once the iteration settles: a -> c, E' -> E)
-__global__ void csalsa_scal_kernel(const double *__restrict__ rs, double *__restrict__ st, double eps, double pv,
-                                   double *__restrict__ out) {
-    const double A0 = rs[0], A1 = rs[1], A2 = rs[2];
+__global__ __launch_bounds__(256) void csalsa_scal_kernel(const double *__restrict__ accp, int nrb, double *__restrict__ st,
+                                                          double eps, double pv, double *__restrict__ out) {
+    // the three sums of the row pass, partials [3][nrb], in the order of reduce_partials_kernel
+    __shared__ double red[4 * 3], tot[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nrb; i += 256) s += accp[(size_t)c * nrb + i];
+        s = ad_wave_sum(s);
+        if (lane == 0) red[c * 4 + w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) tot[threadIdx.x] = (red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1]) + (red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double A0 = tot[0], A1 = tot[1], A2 = tot[2];
     const double n_ve = sqrt(A1 * pv);
     const double sfac = (n_ve <= eps) ? 1.0 : eps / n_ve;
     const double a = 1.0 - sfac, c = st[4], A1p = st[3];
@@ -182,15 +196,34 @@ __global__ __launch_bounds__(AB) void csalsa_post_kernel(const double *__restric
 
 // ---- CoRAL -------------------------------------------------------------------------------------
 // s = (mu1 (u+bu) + mu2 (v+bv)) / mu_ls                                     (CoRAL_v2.m:411, ATy enters spectrally)
+// TVS: also the periodic TV norms of u and v (utils/TVnorm.m:2) for the objective (:425), partials [2][nb]: the two
+// arrays are in flight here anyway (M even; element 2q = (i, j) with i even)
+template <bool TVS>
 __global__ __launch_bounds__(AB) void coral_s_kernel(const double *__restrict__ u, const double *__restrict__ bu,
                                                       const double *__restrict__ v, const double *__restrict__ bv,
                                                       double mu1, double mu2, double mu_ls, double *__restrict__ s,
-                                                      size_t P) {
+                                                      double *__restrict__ partials, unsigned M, unsigned N, size_t P) {
+    double acc[2] = {0, 0};
     AD_LOOP(q, P) {
         const double2 a = AD_LD(u, q), b = AD_LD(bu, q), c = AD_LD(v, q), d = AD_LD(bv, q);
         AD_ST(s, q, make_double2((mu1 * (a.x + b.x) + mu2 * (c.x + d.x)) / mu_ls,
                                  (mu1 * (a.y + b.y) + mu2 * (c.y + d.y)) / mu_ls));
+        if constexpr (TVS) {
+            const unsigned idx = (unsigned)(2 * q), j = idx / M, i = idx - j * M;
+            const size_t lcol = (size_t)(j > 0 ? j - 1 : N - 1) * M + i, up = (size_t)j * M + (i > 0 ? i - 1 : M - 1);
+            const double2 ul = *reinterpret_cast<const double2 *>(u + lcol), vl = *reinterpret_cast<const double2 *>(v + lcol);
+            const double uu = u[up], vu = v[up];
+            {
+                const double h0 = a.x - ul.x, v0 = a.x - uu, h1 = a.y - ul.y, v1 = a.y - a.x;
+                acc[0] += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
+            }
+            {
+                const double h0 = c.x - vl.x, v0 = c.x - vu, h1 = c.y - vl.y, v1 = c.y - c.x;
+                acc[1] += sqrt(h0 * h0 + v0 * v0) + sqrt(h1 * h1 + v1 * v1);
+            }
+        }
     }
+    if constexpr (TVS) ad_store_partials<2>(acc, partials);
 }
 
 // bu += u - x ; bv += v - x ; g1 = x - bu ; g2 = x - bv  (:420-421 and the next prox inputs :401,406)
@@ -503,14 +536,27 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
         a.acc = acc;
         SBTV_TRY(fft_cols_fwd(ctx, c.fp, u, bu, c.S));
         SBTV_TRY(fft_rows(ctx, c.fp, c.S, c.S, a));
-        SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
-        SBTV_TRY(reduce_partials(ctx, acc, 3, fft_rows_blocks(c.fp), rs));
-        hipLaunchKernelGGL(csalsa_scal_kernel, dim3(1), dim3(1), 0, ctx->stream, rs, cst, epsilon, c.parseval, sums);
-        hipLaunchKernelGGL(ad_sub_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, bu, g, P);
-        SBTV_TRY(admm_prox(ctx, pp, g, K, u, spec, &nlaunch, sums + 16, par + 2, opts->chambolle_tol, opts->chambolle_tau));
+        if (fft_cols_inv_step_ok(c.fp)) {
+            SBTV_TRY(fft_cols_inv_sub(ctx, c.fp, c.S, xn, c.inv_scale, bu, g));       // x and the prox input x - bu
+        } else {
+            SBTV_TRY(fft_cols_inv(ctx, c.fp, c.S, xn, c.inv_scale));
+            hipLaunchKernelGGL(ad_sub_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, bu, g, P);
+        }
+        hipLaunchKernelGGL(csalsa_scal_kernel, dim3(1), dim3(256), 0, ctx->stream, acc, fft_rows_blocks(c.fp), cst, epsilon,
+                           c.parseval, sums);
+        RedJobs jb;
+        if (!spec) {
+            SBTV_TRY(admm_prox(ctx, pp, g, K, u, false, &nlaunch, sums + 16, par + 2, opts->chambolle_tol, opts->chambolle_tau));
+        } else {
+            // (admm_prox without its reduction: the step sums are reduced together with the sums of the last pass)
+            SBTV_TRY(prox_iterate(ctx, pp, g, K, u, false, 1, (int)(nlaunch & 1), nullptr));
+            nlaunch += prox_launches(pp, K);
+            jb.add(pp.partials, K, pp.fnblk, sums + 16);
+        }
         hipLaunchKernelGGL(csalsa_post_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn, u, bu, td,
                            (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, partials, (unsigned)M, (unsigned)N, P);
-        SBTV_TRY(reduce_partials(ctx, partials, 5, nb, sums + 2));
+        jb.add(partials, 5, nb, sums + 2);
+        SBTV_TRY(reduce_jobs(ctx, jb));
         SBTV_HIP(ctx, hipGetLastError());
         double *hsl = hslot[outer & 1];
         SBTV_HIP(ctx, hipMemcpyAsync(hsl, sums, sizeof(double) * (16 + (spec ? K : 0)), hipMemcpyDeviceToHost, ctx->stream));
@@ -649,21 +695,31 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
               int *numA, int *numAt, int *n_outer, bool spec_wanted) {
     AdmmCommon c;
     SBTV_TRY(admm_common(ctx, M, N, taps, taille, yd, &c));
+    // The two TV proxes of an iteration are independent (:401,406).  With the same iteration count they run as ONE batch of
+    // two images (own threshold, own duals, own stop rule per image: the batch semantics of the prox): two Chambolle
+    // launches with twice the tiles per outer iteration instead of four (SBTV_CORAL_BATCH=0: one plan per prox)
+    static const bool env_batch = [] {
+        const char *e = getenv("SBTV_CORAL_BATCH");
+        return !(e && e[0] == '0');
+    }();
+    const bool batched = env_batch && opts->TViters == TViters2;
     ProxPlan pu, pv;
-    SBTV_TRY(prox_plan(ctx, M, N, 1, &pu, "prox"));
-    SBTV_TRY(prox_plan(ctx, M, N, 1, &pv, "prox2"));
+    SBTV_TRY(prox_plan(ctx, M, N, batched ? 2 : 1, &pu, batched ? "prox.pair" : "prox"));
+    if (!batched) SBTV_TRY(prox_plan(ctx, M, N, 1, &pv, "prox2"));
     const size_t P = c.P;
     const int nb = ad_blocks(P), nrb = fft_rows_blocks(c.fp);
-    double *xbuf[2], *u, *bu, *v, *bv, *s, *g1, *g2, *par, *partials, *sums, *acc;
+    const bool tv_in_s = !(M & 1) && P < ((size_t)1 << 31);             // TV(u), TV(v) ride in the pass that forms s
+    double *xbuf[2], *u, *bu, *v, *bv, *s, *g1, *g2, *par, *partials, *sums, *acc, *tvpart;
     SBTV_TRY(ws_get_t(ctx, "admm.x0", P, &xbuf[0]));
     SBTV_TRY(ws_get_t(ctx, "admm.x1", P, &xbuf[1]));
-    SBTV_TRY(ws_get_t(ctx, "admm.u", P, &u));
+    SBTV_TRY(ws_get_t(ctx, "admm.uv", 2 * P, &u));                      // [u | v] and [g1 | g2]: the images of the batch
+    v = u + P;
     SBTV_TRY(ws_get_t(ctx, "admm.bu", P, &bu));
-    SBTV_TRY(ws_get_t(ctx, "admm.v", P, &v));
     SBTV_TRY(ws_get_t(ctx, "admm.bv", P, &bv));
     SBTV_TRY(ws_get_t(ctx, "admm.w", P, &s));
-    SBTV_TRY(ws_get_t(ctx, "admm.g", P, &g1));
-    SBTV_TRY(ws_get_t(ctx, "admm.g2", P, &g2));
+    SBTV_TRY(ws_get_t(ctx, "admm.g12", 2 * P, &g1));
+    g2 = g1 + P;
+    SBTV_TRY(ws_get_t(ctx, "admm.tvpart", (size_t)2 * nb, &tvpart));
     SBTV_TRY(ws_get_t(ctx, "admm.par", (size_t)4, &par));               // mu_ls, thr1, thr2
     SBTV_TRY(ws_get_t(ctx, "admm.partials", (size_t)8 * nb, &partials));
     SBTV_TRY(ws_get_t(ctx, "admm.sums", (size_t)96, &sums));            // [0..6] post sums, [8] resid2, [9] TV(u), [10] TV(v), [16..], [48..] step sums
@@ -691,9 +747,11 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
     SBTV_HIP(ctx, hipMemsetAsync(g1, 0, sizeof(double) * P, ctx->stream));
     SBTV_HIP(ctx, hipMemsetAsync(g2, 0, sizeof(double) * P, ctx->stream));
     SBTV_TRY(prox_zero_duals(ctx, pu));                                  // :384-392
-    SBTV_TRY(prox_zero_duals(ctx, pv));
     SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, opts->TViters, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
-    SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, TViters2, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
+    if (!batched) {
+        SBTV_TRY(prox_zero_duals(ctx, pv));
+        SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, TViters2, opts->chambolle_tol, opts->chambolle_tau, false, nullptr));
+    }
 
     // initial objective (:366-368)
     {
@@ -729,7 +787,7 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
     SBTV_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const int K1 = opts->TViters, K2 = TViters2;
     const bool spec = spec_wanted && !(opts->speculate & 2) && !admm_exact_forced() && prox_spec_ok(pu, g1, u, K1) &&
-                      prox_spec_ok(pv, g2, v, K2);
+                      (batched || prox_spec_ok(pv, g2, v, K2));
     const int lag = (spec && (opts->speculate & 1)) ? 1 : 0;
     long long nl_u = 0, nl_v = 0, prox_iters = 0;
     AdmmSlots slots;
@@ -741,14 +799,35 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
         // the two TV proxes with their own warm-started duals (:401,406).  The first outer iteration always runs exactly:
         // its prox inputs x - bu = x - bv are zero and the rule stops at k = 1; its control blocks are re-armed afterwards
         const bool sp = spec && outer >= 2;
+        RedJobs jb;
         if (spec && outer == 2) {
             SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, K1, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
-            SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, K2, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+            if (!batched) SBTV_TRY(prox_reset(ctx, pv, par + 2, 1.0, K2, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
         }
-        SBTV_TRY(admm_prox(ctx, pu, g1, K1, u, sp, &nl_u, sums + 16, par + 1, opts->chambolle_tol, opts->chambolle_tau));
-        SBTV_TRY(admm_prox(ctx, pv, g2, K2, v, sp, &nl_v, sums + 48, par + 2, opts->chambolle_tol, opts->chambolle_tau));
+        if (batched) {
+            // both images in one plan: the step sums of image b land at sums + 16 + b FSTRIDE (= sums + 48 for v)
+            static_assert(FSTRIDE == 32, "the step sums of the second prox are read at sums + 48");
+            if (!sp) {
+                SBTV_TRY(prox_reset(ctx, pu, par + 1, 1.0, K1, opts->chambolle_tol, opts->chambolle_tau, true, nullptr));
+                SBTV_TRY(prox_iterate(ctx, pu, g1, K1, u));
+            } else {
+                SBTV_TRY(prox_iterate(ctx, pu, g1, K1, u, false, 1, (int)(nl_u & 1), nullptr));
+                nl_u += prox_launches(pu, K1);
+                jb.add(pu.partials, FSTRIDE + K1, pu.fnblk, sums + 16);      // reduced at the end of the iteration
+            }
+        } else {
+            SBTV_TRY(admm_prox(ctx, pu, g1, K1, u, sp, &nl_u, sums + 16, par + 1, opts->chambolle_tol, opts->chambolle_tau));
+            SBTV_TRY(admm_prox(ctx, pv, g2, K2, v, sp, &nl_v, sums + 48, par + 2, opts->chambolle_tol, opts->chambolle_tau));
+        }
         // r = ATy + mu1 (u+bu) + mu2 (v+bv) ; x = invLS(r)   (:411-413)  + residual energy (:423, Parseval)
-        hipLaunchKernelGGL(coral_s_kernel, dim3(nb), dim3(AB), 0, ctx->stream, u, bu, v, bv, mu1, mu2, mu_ls, s, P);
+        if (tv_in_s) {
+            hipLaunchKernelGGL(coral_s_kernel<true>, dim3(nb), dim3(AB), 0, ctx->stream, u, bu, v, bv, mu1, mu2, mu_ls, s, tvpart,
+                               (unsigned)M, (unsigned)N, P);
+            jb.add(tvpart, 2, nb, sums + 9);
+        } else {
+            hipLaunchKernelGGL(coral_s_kernel<false>, dim3(nb), dim3(AB), 0, ctx->stream, u, bu, v, bv, mu1, mu2, mu_ls, s, tvpart,
+                               (unsigned)M, (unsigned)N, P);
+        }
         {
             RowsArgs a{};
             a.dir_fwd = 1;
@@ -764,16 +843,19 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
         }
         hipLaunchKernelGGL(coral_post_kernel, dim3(nb), dim3(AB), 0, ctx->stream, xn,
                            (opts->stopcriterion == 2) ? xprev : (const double *)nullptr, u, v, bu, bv, g1, g2, td, partials, P);
-        SBTV_TRY(reduce_partials(ctx, partials, 7, nb, sums));
-        SBTV_TRY(reduce_partials(ctx, acc, 1, nrb, sums + 8));
-        SBTV_TRY(tvnorm_dev(ctx, u, M, N, 1, sums + 9));
-        SBTV_TRY(tvnorm_dev(ctx, v, M, N, 1, sums + 10));
+        jb.add(partials, 7, nb, sums);
+        jb.add(acc, 1, nrb, sums + 8);
+        SBTV_TRY(reduce_jobs(ctx, jb));
+        if (!tv_in_s) {
+            SBTV_TRY(tvnorm_dev(ctx, u, M, N, 1, sums + 9));
+            SBTV_TRY(tvnorm_dev(ctx, v, M, N, 1, sums + 10));
+        }
         SBTV_HIP(ctx, hipGetLastError());
         double *hsl = hslot[outer & 1];
         SBTV_HIP(ctx, hipMemcpyAsync(hsl, sums, sizeof(double) * (sp ? 80 : 12), hipMemcpyDeviceToHost, ctx->stream));
         if (!sp) {
             SBTV_HIP(ctx, hipMemcpyAsync(hsl + 12, pu.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            SBTV_HIP(ctx, hipMemcpyAsync(hsl + 13, pv.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SBTV_HIP(ctx, hipMemcpyAsync(hsl + 13, batched ? pu.ctrl + 1 : pv.ctrl, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
         SBTV_HIP(ctx, hipEventRecord(slots.ev[outer & 1], ctx->stream));
         return 0;

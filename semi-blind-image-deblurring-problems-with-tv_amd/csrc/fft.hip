@@ -1088,6 +1088,21 @@ int fft_cols_inv_step(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }
+int fft_cols_inv_sub(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const double *b, double *g) {
+    if (!fft_cols_inv_step_ok(pl)) return fail(ctx, SBTV_ERR_BADARG, "fft_cols_inv_sub: size not on the wave-granular path");
+    ColsPost post;
+    post.bu_in = b;
+    post.g = g;
+    const dim3 grid(pl.N / TW, pl.batch), block(64 * TW);
+    if (pl.n1 == 1024)
+        hipLaunchKernelGGL((cols_inv_wave_kernel<10, 16, 64>), grid, block, 0, ctx->stream, S, x, pl.tw_n1, pl.tw_M, pl.N, scale,
+                           (const int *)nullptr, post);
+    else
+        hipLaunchKernelGGL((cols_inv_wave_kernel<9, 8, 64>), grid, block, 0, ctx->stream, S, x, pl.tw_n1, pl.tw_M, pl.N, scale,
+                           (const int *)nullptr, post);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
 int fft_cols_inv_myula(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double scale, double *X, const double *prox,
                        const double *Z, const double *sigma2_dev, double gam, double lamb, const RngArgs *rng,
                        const ProxArm *arm) {

@@ -401,6 +401,8 @@ int fft_cols_blocks(const FftPlan &pl);
 bool fft_cols_inv_step_ok(const FftPlan &pl);
 int fft_cols_inv_step(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *y, double scale, double alpha,
                       const int *frozen);
+// x = scale * colIFFT(S) and g = x - b from the column still in registers (sizes of fft_cols_inv_step_ok)
+int fft_cols_inv_sub(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const double *b, double *g);
 int fft_cols_inv_post(sbtv_ctx *ctx, const FftPlan &pl, const double2 *S, double *x, double scale, const int *frozen,
                       const ColsPost &post);
 struct RowsArgs {
@@ -429,6 +431,24 @@ int psf_spectrum_sets(sbtv_ctx *ctx, const FftPlan &pl, const double *const *tap
 // ----------------------------- elementwise (elementwise.hip) ----------------
 // generic deterministic final reduction: out[b*nout + q] = sum_i partials[(b*nout+q)*n + i]
 int reduce_partials(sbtv_ctx *ctx, const double *partials, int nvec, int n, double *out);
+// up to four such reductions in one launch: dst[q][v] = sum_i src[q][v*n[q] + i], v < nvec[q] (unused jobs: nvec = 0)
+struct RedJobs {
+    const double *src[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nvec[4] = {0, 0, 0, 0};
+    int n[4] = {0, 0, 0, 0};
+    void add(const double *s, int nv, int nn, double *d) {
+        for (int q = 0; q < 4; ++q)
+            if (nvec[q] == 0) {
+                src[q] = s;
+                dst[q] = d;
+                nvec[q] = nv;
+                n[q] = nn;
+                return;
+            }
+    }
+};
+int reduce_jobs(sbtv_ctx *ctx, const RedJobs &jb);
 int ew_blocks(size_t P);
 // out4_dev[b*4 + {0,1,2,3}] = sum (a-c)^2, sum a^2, sum c^2, max a
 int pair_sums(sbtv_ctx *ctx, const double *a, const double *c, size_t P, int batch, double *out4_dev);

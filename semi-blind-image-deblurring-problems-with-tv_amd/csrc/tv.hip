@@ -642,6 +642,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
+// the same for up to four sets of vectors in ONE launch (a solver loop ends an iteration with several small reductions,
+// each a launch of a few microseconds on an otherwise idle GPU); same summation order as reduce_partials_kernel
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobs jb) {
+    __shared__ double red[4];
+    int v = blockIdx.x, q = 0;
+    while (q < 3 && v >= jb.nvec[q]) v -= jb.nvec[q++];
+    const int n = jb.n[q];
+    const double *p = jb.src[q] + (size_t)v * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    const double tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) jb.dst[q][v] = tot;
+}
+
 __global__ void copy_duals_kernel(double *__restrict__ dst0, double *__restrict__ dst1,
                                   const double *__restrict__ pbuf, const ProxCtrl *__restrict__ ctrl, size_t P,
                                   int batch) {
@@ -1038,6 +1052,15 @@ int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f) {
     else
         hipLaunchKernelGGL(chambolle_finish_kernel<false>, grid, dim3(TVB), 0, ctx->stream, g, pl.pbuf, pl.ctrl, f,
                            pl.M, pl.N, pl.batch);
+    SBTV_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int reduce_jobs(sbtv_ctx *ctx, const RedJobs &jb) {
+    int tot = 0;
+    for (int q = 0; q < 4; ++q) tot += jb.nvec[q];
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(tot), dim3(256), 0, ctx->stream, jb);
     SBTV_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -168,6 +168,32 @@ def test_coral_matches_oracle(ctx, stop, init, k2):
     assert np.max(np.abs(xg - ref["x"])) < 1e-7
 
 
+def test_coral_batched_proxes_match_oracle_at_1024(ctx, man512):
+    """Equal TViters: the two proxes of an outer iteration run as one batch of two images with their own thresholds
+    (tau1/mu1 != tau2/mu2), optimistic launches from the second iteration on; TV(u), TV(v) come from the pass that forms s."""
+    import sbtv
+    import sbtv_oracle as o
+    x = np.tile(man512, (2, 2))
+    st = _setup(x, seed=7)
+    A, AT, invLS2 = _oracle_handles(st)
+    theta, s2 = 0.03, st["sigma"] ** 2
+    tau1, tau2 = 0.7 * theta * s2, 0.3 * theta * s2
+    mu1, mu2, K = theta / 10, theta / 25, 12
+    ref = o.CoRAL_v2(st["y"], A, tau1, tau2, mu1=mu1, mu2=mu2, AT=AT, invLS=lambda r: invLS2(r, mu1 + mu2), true_x=x,
+                     stopcriterion=1, tolA=0.0, maxiter=K, TViters1=10, TViters2=10, initialization=2)
+    op = sbtv.BlurOperator(sbtv.psf_family("gaussian", 7, st["p_true"])[0])
+    got = sbtv.CoRAL(st["y"], op, tau1, tau2, "MU1", mu1, "MU2", mu2, "AT", op.T, "LS", op.LS(mu1 + mu2),
+                     "TVINITIALIZATION1", 1, "TVITERS1", 10, "TVINITIALIZATION2", 1, "TVITERS2", 10, "STOPCRITERION", 1,
+                     "TOLERANCEA", 0.0, "MAXITERA", K, "TRUE_X", x, "INITIALIZATION", 2, "VERBOSE", 0)
+    xg, numA, numAt, objective, distance, times, mses = got
+    assert len(objective) == len(ref["objective"]) == K + 1
+    assert (numA, numAt) == (ref["numA"], ref["numAt"])
+    np.testing.assert_allclose(objective, ref["objective"], rtol=1e-9)
+    np.testing.assert_allclose(mses, ref["mses"], rtol=1e-9)
+    np.testing.assert_allclose(distance, ref["distance"], rtol=1e-7)
+    assert np.max(np.abs(xg - ref["x"])) < 1e-7
+
+
 def test_coral_split_equals_salsa_fixed_point(ctx, cman256):
     """tau1 + tau2 = tau poses the same problem as SALSA_v2 with tau: both front-ends land on (nearly) the same image."""
     import sbtv
