@@ -861,6 +861,9 @@ __global__ __launch_bounds__(64) void psf_spectrum_kernel(PsfSets ps, int taille
 }
 
 #include "fft_wave.inc"
+#ifdef SBTV_LAB
+#include "fft_rows_sub.inc"
+#endif
 #include "fft_any.inc"
 
 // ---------------------------------------------------------------------------
@@ -885,6 +888,20 @@ static inline bool rows_wave() {
         return e && e[0] == 'w' && e[1] == 'a';
     }();
     return on;
+#else
+    return false;
+#endif
+}
+// lab build, SBTV_ROWS_SUB=1: the row pass of the wave-granular sizes as four wave-local sub-transforms per row
+// (rows_sub_kernel, fft_rows_sub.inc; operator spectra sub-row-major).  Round 3's fourth structural attempt on this pass: it
+// ties with the software-pipelined kernel on every loop (profiles/r03_rows_sub_ab.md), so the default library keeps that one
+static inline bool rows_sub() {
+#ifdef SBTV_LAB
+    static const bool on = [] {
+        const char *e = getenv("SBTV_ROWS_SUB");
+        return e && e[0] == '1';
+    }();
+    return on && !rows_wave();
 #else
     return false;
 #endif
@@ -964,7 +981,7 @@ int fft_plan(sbtv_ctx *ctx, int M, int N, int batch, FftPlan *pl) {
     // operator spectra: row-major U[k][l] with a padded leading dimension for the wave-granular row kernel, the
     // column-major U[l][k] (leading dimension M/2 + 1, u_ld = 0) otherwise
     pl->u_ld = (pl->wave && rows_wave()) ? N + 16 : 0;
-    pl->u_tiled = (pl->wave && !rows_wave() && u_tiled_wanted()) ? 1 : 0;
+    pl->u_tiled = (pl->wave && rows_sub()) ? 2 : ((pl->wave && !rows_wave() && u_tiled_wanted()) ? 1 : 0);   // 2: U[k][l%4][l/4]
     pl->u_img = pl->u_ld ? (size_t)(pl->n1 + 1) * pl->u_ld : (size_t)(pl->n1 + 1) * N;
     SBTV_TRY(twiddle_get(ctx, pl->n1, &pl->tw_n1));
     SBTV_TRY(twiddle_get(ctx, M, &pl->tw_M));
@@ -1200,7 +1217,7 @@ bool fft_rows_csalsa_ok(const FftPlan &pl) {
 }
 int fft_rows_blocks(const FftPlan &pl) {
     if (pl.generic) return ANY_SPEC_BLOCKS;
-    if (pl.wave) return rows_wave() ? pl.n1 / 2 : (rows_pipe(0) ? pl.n1 / 4 : pl.n1 / rows_wg_rk());
+    if (pl.wave) return (rows_wave() || rows_sub()) ? pl.n1 / 2 : (rows_pipe(0) ? pl.n1 / 4 : pl.n1 / rows_wg_rk());
     return pl.n1 / rows_rk(pl);
 }
 
@@ -1243,6 +1260,29 @@ static void launch_rows_pipe(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams 
     }
 #undef SBTV_ROWS_OP
 }
+
+#ifdef SBTV_LAB
+template <int L>
+static void launch_rows_sub(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
+    const dim3 grid(pl.n1 / 2, pl.batch), block((1 << L) / 4);
+#define SBTV_ROWS_OP(OP_)                                                                                     \
+    case OP_: hipLaunchKernelGGL((rows_sub_kernel<L, OP_>), grid, block, 0, ctx->stream, p); break;
+    switch (p.op) {
+        SBTV_ROWS_OP(OP_NONE)
+        SBTV_ROWS_OP(OP_MUL_H)
+        SBTV_ROWS_OP(OP_MUL_HC)
+        SBTV_ROWS_OP(OP_INVLS)
+        SBTV_ROWS_OP(OP_SALSA)
+        SBTV_ROWS_OP(OP_RESID)
+        SBTV_ROWS_OP(OP_GRAD)
+        SBTV_ROWS_OP(OP_ATA)
+        SBTV_ROWS_OP(OP_GRADF)
+        SBTV_ROWS_OP(OP_CSALSA)
+        default: break;
+    }
+#undef SBTV_ROWS_OP
+}
+#endif
 
 template <int L, int RK, bool TILED = false>
 static void launch_rows(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
@@ -1291,6 +1331,14 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     if (pl.generic) return any_rows(ctx, pl, p, Sout);
     const int L = ilog2(pl.N);
     if (L > 12) return fail(ctx, SBTV_ERR_SIZE, "row FFT: N must be <= 4096");
+#ifdef SBTV_LAB
+    if (pl.wave && rows_sub()) {
+        if (L == 11) launch_rows_sub<11>(ctx, pl, p);
+        else launch_rows_sub<10>(ctx, pl, p);
+        SBTV_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+#endif
     if (pl.wave && !rows_wave()) {
         if (rows_pipe(L)) {
             // software-pipelined row pass (two row pairs per workgroup, loads in flight across the arithmetic)
@@ -1389,15 +1437,15 @@ int psf_spectrum_sets(sbtv_ctx *ctx, const FftPlan &pl, const double *const *tap
     const size_t elems = (size_t)(pl.n1 + 1) * pl.N * pl.batch;
     int lch = (int)(elems >> 19);                       // 512^2, 1024^2: 1;  2048^2: 4;  8 x 1024^2: 8
     lch = lch < 1 ? 1 : (lch > 16 ? 16 : lch);
-    if (pl.u_ld) {
+    if (pl.u_ld || pl.u_tiled == 2) {
         const dim3 gridw((pl.N + thr - 1) / thr, (pl.n1 + 1 + lch - 1) / lch, pl.batch);
         for (int q = 0; q < nsets; ++q) {
             if (taille == 7)
                 hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<7>, gridw, dim3(thr), 0, ctx->stream, taps_dev[q], taille, U[q],
-                                   pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+                                   pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld ? pl.u_ld : pl.N, pl.u_tiled == 2);
             else
                 hipLaunchKernelGGL(psf_spectrum_rowmajor_kernel<0>, gridw, dim3(thr), 0, ctx->stream, taps_dev[q], taille, U[q],
-                                   pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld);
+                                   pl.n1, pl.M, pl.N, pl.tw_M, pl.tw_N, lch, pl.u_ld ? pl.u_ld : pl.N, pl.u_tiled == 2);
         }
         SBTV_HIP(ctx, hipGetLastError());
         return 0;
