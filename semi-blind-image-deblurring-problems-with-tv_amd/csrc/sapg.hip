@@ -162,7 +162,7 @@ enum { SAPG_PH_GRADS = 1, SAPG_PH_UPDATE = 2, SAPG_PH_WARMUP = 4 };
 
 __global__ __launch_bounds__(256) void sapg_update_kernel(SapgDev u, int phase) {
 #pragma clang fp contract(off)
-    __shared__ double sf[225], se0[225], se1[225], ssum[3];
+    __shared__ double sf[256], se0[256], se1[256], ssum[3];
     const int B = u.batch, tid = threadIdx.x, t2 = u.taille * u.taille;
     double *lam_d = u.par + (size_t)3 * t2 * u.nspec, *sig_d = lam_d + B, *step_d = sig_d + B;
     if (u.pctrl && (phase & (SAPG_PH_WARMUP | SAPG_PH_GRADS))) {
@@ -279,8 +279,42 @@ __global__ __launch_bounds__(256) void sapg_update_kernel(SapgDev u, int phase) 
     }
     __threadfence_block();
     __syncthreads();
-    if (u.params_move) {
-        // taps and derivative taps of the new PSF parameters, one spectrum set after the other (sbtv_psf_taps)
+    if (u.params_move && t2 <= 64) {
+        // taps and derivative taps of the new PSF parameters (sbtv_psf_taps): one WAVE per spectrum set, four sets at a time
+        // (a 7 x 7 mask is 49 lanes; the sums run over the taps in MATLAB's column-major order on lane 0, as below)
+        const int w = tid >> 6, lane = tid & 63;
+        for (int sset = w; sset < u.nspec; sset += 4) {
+            const SapgChain c = u.chain[sset];
+            const double pv[3] = {c.p0, u.kind == 2 ? 0.0 : c.p1, u.kind == 0 ? u.phi : 0.0};
+            double f = 0.0, e0 = 0.0, e1 = 0.0;
+            if (lane < t2) psf_taps_point(u.kind, u.taille, pv, lane, &f, &e0, &e1);
+            sf[tid] = f;
+            se0[tid] = e0;
+            se1[tid] = e1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double a = 0, a0 = 0, a1 = 0;
+            if (lane == 0) {
+                for (int q = 0; q < t2; ++q) {
+                    a += sf[w * 64 + q];
+                    a0 += se0[w * 64 + q];
+                    a1 += se1[w * 64 + q];
+                }
+            }
+            a = __shfl(a, 0, 64);
+            a0 = __shfl(a0, 0, 64);
+            a1 = __shfl(a1, 0, 64);
+            if (lane < t2) {
+                u.par[(size_t)sset * t2 + lane] = f / a;
+                u.par[(size_t)t2 * u.nspec + (size_t)sset * t2 + lane] = (e0 * a - f * a0) / (a * a);
+                u.par[(size_t)2 * t2 * u.nspec + (size_t)sset * t2 + lane] = (e1 * a - f * a1) / (a * a);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (u.params_move) {
+        // masks above 8 x 8: one spectrum set after the other on the whole workgroup
         for (int sset = 0; sset < u.nspec; ++sset) {
             const SapgChain c = u.chain[sset];
             const double pv[3] = {c.p0, u.kind == 2 ? 0.0 : c.p1, u.kind == 0 ? u.phi : 0.0};
