@@ -499,6 +499,7 @@ struct RowsParams {
     int n1;                 // rows of S per image
     int fwd, inv, op;
     int shared_spec;        // 1: H / Y / D1 / D2 hold ONE spectrum shared by every image of the batch
+    int fold;               // pipelined row kernel: > 0 = the batch folded into grid.x (see the kernel), else 0
     size_t u_img;           // elements of one operator spectrum per image
     int u_ld;               // leading dimension of the row-major operator spectra (tiled mode)
     int u_tiled;            // operator spectra in the tiled layout U[(l/4)][k][l%4], k = 0..n1
@@ -1257,8 +1258,17 @@ static void launch_rows_wave(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams 
 #endif
 
 template <int L>
-static void launch_rows_pipe(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p) {
-    const dim3 grid(pl.n1 / 4, pl.batch), block((1 << L) / 4);
+static void launch_rows_pipe(sbtv_ctx *ctx, const FftPlan &pl, const RowsParams &p0) {
+    // chains sharing one spectrum set: fold the batch into grid.x (needs a row-block count per image that is a multiple of
+    // the 8 XCDs, so that every XCD's share of the folded list holds whole groups of `batch` workgroups)
+    static const bool fold_wanted = [] {
+        const char *e = getenv("SBTV_ROWS_FOLD");
+        return !(e && e[0] == '0');
+    }();
+    RowsParams p = p0;
+    const bool fold = fold_wanted && p.shared_spec && pl.batch > 1 && ((pl.n1 / 4) % 8 == 0);
+    p.fold = fold ? pl.batch : 0;
+    const dim3 grid(fold ? (pl.n1 / 4) * pl.batch : pl.n1 / 4, fold ? 1 : pl.batch), block((1 << L) / 4);
 #define SBTV_ROWS_OP(OP_)                                                                                     \
     case OP_: hipLaunchKernelGGL((rows_pipe_kernel<L, OP_>), grid, block, 0, ctx->stream, p); break;
     switch (p.op) {
@@ -1340,6 +1350,7 @@ int fft_rows(sbtv_ctx *ctx, const FftPlan &pl, const double2 *Sin, double2 *Sout
     p.inv = a.dir_inv;
     p.op = a.op;
     p.shared_spec = a.shared_spec;
+    p.fold = 0;
     p.u_img = pl.u_img;
     p.u_ld = pl.u_ld;
     p.u_tiled = pl.u_tiled;

@@ -60,3 +60,12 @@ def test_fft_passes_of_the_salsa_loop_do_not_spill():
     # compiler parks 4 registers (20 bytes per lane) in scratch; more than a handful would show in the loop
     k = _find(rep, "rows_pipe_kernelILi11ELi4E")
     assert k["ScratchSize"] <= 32 and k["VGPRs Spill"] <= 6 and k["Occupancy"] == 2, k
+    # OP_CSALSA carries a fourth spectrum (read and written): 27 registers in scratch with Y requested after the forward
+    # transform (46 with all operands up front: DESIGN.md section 3.4); the 1024-point variant has room
+    k = _find(rep, "rows_pipe_kernelILi11ELi9E")
+    assert k["ScratchSize"] <= 128 and k["VGPRs Spill"] <= 32, k
+    k = _find(rep, "rows_pipe_kernelILi10ELi9E")
+    assert k["ScratchSize"] == 0, k
+    # C-SALSA's inverse column pass with x - bu as its epilogue
+    k = _find(rep, "cols_inv_wave_kernelILi10ELi16ELi64E")
+    assert k["ScratchSize"] == 0 and k["Occupancy"] >= 2, k

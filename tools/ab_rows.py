@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for rnd in range(rounds):
     for v in ("1", "0"):
-        env = dict(os.environ, SBTV_ROWS_SUB=v, SBTV_LIBRARY=os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd", "lib", "libsbtv_lab.so"))
+        lab = os.environ.get("AB_ROWS_LIB", os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd", "lib", "libsbtv_lab.so"))
+        env = dict(os.environ, SBTV_ROWS_SUB=v, SBTV_LIBRARY=lab)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"], env=env, capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
