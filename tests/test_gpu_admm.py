@@ -194,6 +194,48 @@ def test_coral_batched_proxes_match_oracle_at_1024(ctx, man512):
     assert np.max(np.abs(xg - ref["x"])) < 1e-7
 
 
+CORAL_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "semi-blind-image-deblurring-problems-with-tv_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import sbtv
+from conftest import synth_image
+res = {}
+for tag, (M, N) in (("a", (2048, 1024)), ("b", (192, 256)), ("c", (100, 90))):
+    x = synth_image(M, N, 11)
+    st = sbtv.demo_setup("gaussian", x, np.random.default_rng(4).standard_normal(x.shape), evMax=1.0)
+    op = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    theta, s2 = 0.03, st["sigma"] ** 2
+    got = sbtv.CoRAL(st["y"], op, 0.6 * theta * s2, 0.4 * theta * s2, "MU1", theta / 10, "MU2", theta / 20, "AT", op.T,
+                     "LS", op.LS(theta / 10 + theta / 20), "TVINITIALIZATION1", 1, "TVITERS1", 10, "TVINITIALIZATION2", 1,
+                     "TVITERS2", 10, "STOPCRITERION", 2, "TOLERANCEA", 0.0, "MAXITERA", 12, "TRUE_X", x, "VERBOSE", 0)
+    for nm, v in zip(("x", "obj", "dist", "mses"), (got[0], got[3], got[4], got[6])):
+        res[tag + "_" + nm] = np.asarray(v)
+np.savez(sys.argv[1], **res)
+"""
+
+
+def test_coral_batched_and_separate_proxes_agree(tmp_path):
+    """One batch of two images (default when TViters1 == TViters2) against one plan per prox (SBTV_CORAL_BATCH=0): the prox of
+    an image does not depend on what else is in its batch, so the runs agree to the last bit - at 2048 x 1024 (wave-granular
+    FFT kernels), 192 x 256 and 100 x 90 (chirp-z path)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(name, env):
+        out = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", CORAL_CHILD % {"root": root}, out], check=True, env=e, timeout=900)
+        return np.load(out)
+    a, b = run("batched", {}), run("separate", {"SBTV_CORAL_BATCH": "0"})
+    for key in a.files:
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+
+
 def test_coral_split_equals_salsa_fixed_point(ctx, cman256):
     """tau1 + tau2 = tau poses the same problem as SALSA_v2 with tau: both front-ends land on (nearly) the same image."""
     import sbtv
