@@ -273,6 +273,9 @@ struct ProxPlan {
     size_t part_stride;           // doubles per set
     unsigned *counters;           // [batch] arrival tickets (in-kernel stop-rule path)
     const int *order;             // [fnblk] workgroup -> tile of the 128-row tile kernel (null: the arithmetic XCD-chunk order)
+    // mixed tiling (mix_nfull > 0): tile ids below mix_nfull are 128-row tiles on a grid of mix_nfi tile rows, the others
+    // 64-row one-row-per-lane tiles on mix_nhi tile rows starting at image row mix_row0; dispatched last (tv.hip)
+    int mix_nfull, mix_nfi, mix_nhi, mix_row0;
 };
 int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan, const char *tag = "prox");
 // (Re)initialise the control blocks: k=0, done=0 and the per-image lambda from a

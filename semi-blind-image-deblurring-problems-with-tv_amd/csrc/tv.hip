@@ -226,6 +226,15 @@ constexpr int FHL = FHJ + 1;             // left column halo: one more, because 
                                          // last launch needs py(i, j-1) of the FINAL iterate left of the core
 constexpr int FRI = 128;                 // region rows
 constexpr int FCI = FRI - 2 * FH;        // core rows   (116)
+// one-row-per-lane tiles (tv_fused1.inc)
+constexpr int F1RI = 64;                 // region rows
+constexpr int F1HT = FHJ + 1;            // halo above the core (the f epilogue needs px(i-1) of the final iterate)
+constexpr int F1HB = FHJ;                // halo below
+constexpr int F1CI = F1RI - F1HT - F1HB; // core rows (53)
+// mixed launch of the 128-row kernel: its last workgroups work on 64-row tiles (see prox_plan)
+struct FusedMix {
+    int nfull, nhi, row0;                // 128-row tiles (ids below nfull), tile rows of the 64-row part, its first image row
+};
 // tuning parameters: columns per wave (cj) and waves per block (nw): region columns = nw*cj,
 // core columns = nw*cj - 2 FHJ; minw = waves per SIMD requested from the register allocator
 struct FusedVariant { int cj; int nw; int minw; int fast; int rpl; };   // rpl = rows per lane (2: tv_fused.inc, 1: tv_fused1.inc)
@@ -733,6 +742,47 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
         geometry(4, 8, 1);
         pl->minw = 4;
     }
+    // Mixed tiling of ONE large image on the shipped geometry (lab build, SBTV_TAIL_HALF=1).  A launch of T 128-row tiles runs
+    // as T / S rounds of S = 2 workgroups x CUs, and in its last ~11 us (one workgroup life) the slots run empty one by one.
+    // The idea: as many 128-row tile rows as fill whole rounds and the rest of the image in 64-row tiles (half the work per
+    // workgroup, dispatched last through the order table), so that the slots run empty over half that time.  Same pixels,
+    // same arithmetic per pixel; only the grouping of the error partials changes.  Measured: 63-65 us per launch against 60
+    // with 196, 392 or 588 half tiles (profiles/r03_chambolle_tail.md): the one-row-per-lane body costs more per pixel
+    // than the shorter tail gives back.  Kept in the lab build as the measured alternative.
+    pl->mix_nfull = pl->mix_nfi = pl->mix_nhi = pl->mix_row0 = 0;
+#ifdef SBTV_LAB
+    {
+        static const bool env_on = [] {
+            const char *e = getenv("SBTV_TAIL_HALF");
+            return e && e[0] == '1';
+        }();
+        static const bool order_off = [] {
+            const char *e = getenv("SBTV_TILE_ORDER");
+            return e && e[0] == '0';
+        }();
+        const int slots = 2 * ctx->cu_count;
+        if (env_on && !order_off && !g_fused_forced && batch == 1 && pl->rpl == 2 && pl->cj == 4 && pl->nw == 8 && pl->minw == 4 &&
+            (M % 2 == 0) && slots > 0 && pl->fnblk > 2 * 256) {
+            const int tj_n = pl->ftiles_j;
+            int nfi = ((pl->fnblk / slots) * slots) / tj_n;           // tile rows that fit the complete rounds
+            if (nfi > pl->ftiles_i - 1) nfi = pl->ftiles_i - 1;
+            static const int env_rows = [] {                          // SBTV_TAIL_ROWS=r: the last r 128-row tile rows instead
+                const char *e = getenv("SBTV_TAIL_ROWS");
+                return e ? atoi(e) : 0;
+            }();
+            if (env_rows > 0) nfi = pl->ftiles_i - env_rows;
+            const int row0 = nfi * FCI;
+            if (nfi >= 1 && row0 < M) {
+                const int nhi = (M - row0 + F1CI - 1) / F1CI;
+                pl->mix_nfi = nfi;
+                pl->mix_nhi = nhi;
+                pl->mix_row0 = row0;
+                pl->mix_nfull = nfi * tj_n;
+                pl->fnblk = pl->mix_nfull + nhi * tj_n;
+            }
+        }
+    }
+#endif
     // Streaming pipeline kernel (tv_pipe.inc): bands of PCI core rows x column segments, one workgroup per CU.
     // OPT-IN (SBTV_PROX_PIPE=1, any even M): on MI355X it does 1.34 x instead of 1.68 x the arithmetic and a third of
     // the memory traffic, but one barrier per column step with ~100 instructions of work per wave in between leaves
@@ -795,21 +845,31 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
             int *od = nullptr;
             // one table per shape, built once per context (the name carries the shape)
             const std::string name = "prox.order." + std::to_string(M) + "x" + std::to_string(N) + "." + std::to_string(pl->cj) +
-                                     "." + std::to_string(pl->nw);
+                                     "." + std::to_string(pl->nw) + (pl->mix_nfull ? ".mix" + std::to_string(pl->mix_nfi) : std::string());
             const bool built = ctx->ws.find(name) != ctx->ws.end();
             SBTV_TRY(ws_get_t(ctx, name.c_str(), (size_t)nt, &od));
             if (!built) {
                 std::vector<int> h(nt);
-                const int q8 = nt >> 3, r8 = nt & 7, ti_n = pl->ftiles_i, tj_n = pl->ftiles_j;
+                const int q8 = nt >> 3, r8 = nt & 7, tj_n = pl->ftiles_j;
+                // 128-row tiles: ids 0 .. nf-1 on ti_n tile rows; mixed tiling: 64-row tiles nf .. nt-1 on mix_nhi tile rows
+                const int nf = pl->mix_nfull ? pl->mix_nfull : nt, ti_n = pl->mix_nfull ? pl->mix_nfi : pl->ftiles_i;
+                const int fq8 = nf >> 3, fr8 = nf & 7;
+                int half_next = nf;
                 for (int x = 0; x < 8; ++x) {
-                    const int c0 = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8), len = q8 + (x < r8 ? 1 : 0);
+                    // this XCD's workgroup ids are o * 8 + x, o = 0 .. cnt-1: first its contiguous chunk of the 128-row tiles
+                    // (border tiles before interior ones), then a contiguous run of 64-row tiles (roughly the same columns)
+                    const int cnt = q8 + (x < r8 ? 1 : 0);
+                    const int c0 = (x < fr8 ? x * (fq8 + 1) : fr8 * (fq8 + 1) + (x - fr8) * fq8);
+                    int len = fq8 + (x < fr8 ? 1 : 0);
+                    if (len > cnt) len = cnt;
                     int o = 0;
                     for (int pass = 0; pass < 2; ++pass)
                         for (int t2 = c0; t2 < c0 + len; ++t2) {
                             const int ti = t2 % ti_n, tj = t2 / ti_n;
-                            const bool border = (ti == 0 || ti == ti_n - 1 || tj == 0 || tj == tj_n - 1);
+                            const bool border = (ti == 0 || (!pl->mix_nfull && ti == ti_n - 1) || tj == 0 || tj == tj_n - 1);
                             if (border == (pass == 0)) h[(size_t)(o++) * 8 + x] = t2;      // workgroup id = o * 8 + x
                         }
+                    while (o < cnt) h[(size_t)(o++) * 8 + x] = half_next++;
                 }
                 SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 SBTV_HIP(ctx, hipMemcpy(od, h.data(), sizeof(int) * nt, hipMemcpyHostToDevice));
@@ -960,12 +1020,27 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
                                g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
-                               redo, f_out, write_f, pl.counters, kflags, sj, pl.order);                     \
+                               redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0});  \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj, pl.order);    \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0}); \
     }
+#ifdef SBTV_LAB
+            if (!pl.pipe && pl.rpl == 2 && pl.mix_nfull > 0) {
+                // mixed tiling (shipped geometry only, see prox_plan): the 128-row grid has mix_nfi tile rows
+                launched = true;
+                const FusedMix mix{pl.mix_nfull, pl.mix_nhi, pl.mix_row0};
+                if (g_fused.fast)
+                    hipLaunchKernelGGL((chambolle_fused_kernel<4, 8, 4, true, true>), fgrid, dim3(64 * 8), 0, ctx->stream, g, pl.pbuf,
+                                       pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.mix_nfi, pl.fnblk, steps, redo, f_out, write_f,
+                                       pl.counters, kflags, sj, pl.order, mix);
+                else
+                    hipLaunchKernelGGL((chambolle_fused_kernel<4, 8, 4, false, true>), fgrid, dim3(64 * 8), 0, ctx->stream, g, pl.pbuf,
+                                       pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.mix_nfi, pl.fnblk, steps, redo, f_out, write_f,
+                                       pl.counters, kflags, sj, pl.order, mix);
+            } else
+#endif
             SBTV_FUSED_CASE(4, 8, 4)
 #ifdef SBTV_LAB
             SBTV_FUSED_CASE(8, 4, 2)

@@ -223,3 +223,37 @@ def test_lab_row_pass_variants_agree_at_the_wave_granular_sizes(tmp_path):
         for key in ref.files:
             scale = float(np.max(np.abs(ref[key])))
             assert np.max(np.abs(got[key] - ref[key])) <= 1e-10 * scale, (name, key)
+
+
+TAIL_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "semi-blind-image-deblurring-problems-with-tv_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import sbtv
+from conftest import synth_image
+g = synth_image(2048, 2048, 13) + np.random.default_rng(5).standard_normal((2048, 2048))
+f, px, py, k, err = sbtv.chambolle_prox_TV_stop(g, "lambda", 7.0, "maxiter", 25, return_info=True)
+f2, px2, py2, k2, err2 = sbtv.chambolle_prox_TV_stop(g, "lambda", 7.0, "maxiter", 10, "dualvars", np.hstack([px, py]), return_info=True)
+np.savez(sys.argv[1], f=f, px=px, py=py, k=k, err=err, f2=f2, px2=px2, k2=k2, err2=err2)
+"""
+
+
+def test_lab_mixed_tiling_agrees_with_the_128_row_tiles(tmp_path):
+    """SBTV_TAIL_HALF=1 (lab build): the last workgroups of a launch work on 64-row tiles (one row per lane) below the
+    128-row ones, three splits of the tile rows; cold prox of 25 iterations and a warm-started one of 10 at 2048 x 2048."""
+    def run(name, env):
+        out = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", TAIL_CHILD % {"root": ROOT}, out], check=True, env=e, timeout=900)
+        return np.load(out)
+    ref = run("default", {})
+    for name, env in (("auto", dict(LAB, SBTV_TAIL_HALF="1")), ("rows1", dict(LAB, SBTV_TAIL_HALF="1", SBTV_TAIL_ROWS="1")),
+                      ("rows2", dict(LAB, SBTV_TAIL_HALF="1", SBTV_TAIL_ROWS="2"))):
+        got = run(name, env)
+        assert int(got["k"][0]) == int(ref["k"][0]) == 25 and int(got["k2"][0]) == int(ref["k2"][0]) == 10
+        for key in ("err", "err2"):
+            assert float(got[key][0]) == pytest.approx(float(ref[key][0]), rel=1e-12), (name, key)
+        for key in ("f", "px", "py", "f2", "px2"):
+            np.testing.assert_allclose(got[key], ref[key], rtol=1e-12, atol=1e-12, err_msg=name + " " + key)

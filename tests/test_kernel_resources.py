@@ -41,10 +41,13 @@ def _find(rep, *parts):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_fused_chambolle_kernel_keeps_four_waves_per_simd_without_scratch():
-    k = _find(_report("tv.hip"), "chambolle_fused_kernelILi4ELi8ELi4ELb1E")
-    assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, k
-    assert k["VGPRs"] <= 128 and k["Occupancy"] == 4, k
-    assert k["LDS Size"] <= 80 * 1024, k            # two workgroups per CU
+    rep = _report("tv.hip")
+    # (...Lb1ELb1E, the mixed launch whose last workgroups run the one-row-per-lane body, exists in the lab build only)
+    for name in ("chambolle_fused_kernelILi4ELi8ELi4ELb1ELb0E",):
+        k = _find(rep, name)
+        assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (name, k)
+        assert k["VGPRs"] <= 128 and k["Occupancy"] == 4, (name, k)
+        assert k["LDS Size"] <= 80 * 1024, (name, k)            # two workgroups per CU
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
