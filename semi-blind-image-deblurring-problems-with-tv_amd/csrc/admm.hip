@@ -384,6 +384,12 @@ inline bool admm_fired_early(const double *stepsums, int K, double tol) {
         if (!(sqrt(stepsums[k - 1]) > tol)) return true;
     return false;
 }
+// the step sums of launches that sum a subset of the pixels are lower bounds (ProxPlan::esub_off): are they still far from tol^2?
+inline bool admm_sums_near_tol(const double *stepsums, int K, double tol) {
+    for (int k = 1; k <= K; ++k)
+        if (!(stepsums[k - 1] > ESUB_MARGIN * tol * tol)) return true;
+    return false;
+}
 
 // Per-iteration scalars travel through two pinned slots; an event per slot tells the host (which runs one iteration
 // ahead) when slot `outer & 1` holds the scalars of iteration `outer`.
@@ -632,6 +638,7 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
             fired = true;
             return 0;
         }
+        if (spec && !pp.esub_off && admm_sums_near_tol(hsl + 16, K, opts->chambolle_tol)) pp.esub_off = 1;
         prox_iters += spec ? K : *reinterpret_cast<const int *>(hsl + 8);
         h_numAt += 1;
         h_numA += 1;
@@ -869,6 +876,8 @@ int coral_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps,
             fired = true;
             return 0;
         }
+        if (sp && (admm_sums_near_tol(hsl + 16, K1, opts->chambolle_tol) || admm_sums_near_tol(hsl + 48, K2, opts->chambolle_tol)))
+            pu.esub_off = pv.esub_off = 1;
         prox_iters += sp ? (long long)(K1 + K2)
                          : (long long)(*reinterpret_cast<const int *>(hsl + 12) + *reinterpret_cast<const int *>(hsl + 13));
         h_numA += 1;

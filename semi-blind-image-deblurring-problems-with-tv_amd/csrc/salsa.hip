@@ -574,6 +574,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                         break;
                     }
                 if (fired_early) break;
+                // the sums of launches that sum a subset of the pixels are lower bounds: long before they can come near
+                // tol^2 the launches of this solve go back to the full sums (ProxPlan::esub_off)
+                for (int k = 1; k <= opts->TViters && !pp.esub_off; ++k)
+                    if (!(ps[k - 1] > ESUB_MARGIN * opts->chambolle_tol * opts->chambolle_tol)) pp.esub_off = 1;
             }
             prox_iters_run += (long long)prox_k;
             ctx->calls += 2;   // invLS + A (callcounter)

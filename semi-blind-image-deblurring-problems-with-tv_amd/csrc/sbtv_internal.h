@@ -276,6 +276,11 @@ struct ProxPlan {
     // mixed tiling (mix_nfull > 0): tile ids below mix_nfull are 128-row tiles on a grid of mix_nfi tile rows, the others
     // 64-row one-row-per-lane tiles on mix_nhi tile rows starting at image row mix_row0; dispatched last (tv.hip)
     int mix_nfull, mix_nfi, mix_nhi, mix_row0;
+    // optimistic launches (prox_iterate spec == 1) sum their error terms over a subset of the pixels (a lower bound of the
+    // step sums: enough to PROVE that the stop rule cannot have fired, tv_fused.inc ESUB).  A solver loop sets this to 1 once
+    // the step sums it reads come within ESUB_MARGIN of tol^2: from then on its launches sum every pixel again, so that a
+    // solve whose prox converges does not take the exact path because of the looser bound
+    int esub_off;
 };
 int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *plan, const char *tag = "prox");
 // (Re)initialise the control blocks: k=0, done=0 and the per-image lambda from a
@@ -291,6 +296,7 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);  
 // cold = true: start from px = py = 0 without reading (or requiring the caller to clear) the dual buffer; the
 // control block must have been reset with keep_cur = false.
 constexpr int FSMAX = 10;     // most iterations any fused Chambolle kernel runs per LAUNCH
+constexpr double ESUB_MARGIN = 32.0;    // see ProxPlan::esub_off (step sums move by a few per cent per outer iteration, the host is one behind)
 constexpr int FSTRIDE = 32;   // step slots of the error partials [batch][FSTRIDE][nblk]: most iterations of an optimistic prox
 // ---- SALSA collector: what it reduces (salsa.hip launches it; the Chambolle kernels can host its blocks, tv_fused.inc)
 constexpr int SALSA_TAGS = 8 + FSTRIDE;   // completion tags per image: 8 scalars + FSTRIDE prox step sums

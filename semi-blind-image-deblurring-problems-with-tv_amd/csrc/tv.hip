@@ -750,6 +750,7 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
     // with 196, 392 or 588 half tiles (profiles/r03_chambolle_tail.md): the one-row-per-lane body costs more per pixel
     // than the shorter tail gives back.  Kept in the lab build as the measured alternative.
     pl->mix_nfull = pl->mix_nfi = pl->mix_nhi = pl->mix_row0 = 0;
+    pl->esub_off = 0;
 #ifdef SBTV_LAB
     {
         static const bool env_on = [] {
@@ -1026,6 +1027,19 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
                                pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0}); \
     }
+            // optimistic ping-pong launches of a solver loop (spec == 1: the caller only CHECKS the rule afterwards): the error
+            // sums run over a quarter of the columns (tv_fused.inc, ESUB); SBTV_ERR_SUBSET=0: all columns
+            static const bool esub_wanted = [] {
+                const char *e = getenv("SBTV_ERR_SUBSET");
+                return !(e && e[0] == '0');
+            }();
+            if (esub_wanted && !pl.esub_off && spec == 1 && !redo && !pl.pipe && pl.rpl == 2 && pl.cj == 4 && pl.nw == 8 && pl.minw == 4 &&
+                pl.mix_nfull == 0 && g_fused.fast) {
+                launched = true;
+                hipLaunchKernelGGL((chambolle_fused_kernel<4, 8, 4, true, false, true>), fgrid, dim3(64 * 8), 0, ctx->stream, g, pl.pbuf,
+                                   pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, redo, f_out, write_f,
+                                   pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0});
+            } else
 #ifdef SBTV_LAB
             if (!pl.pipe && pl.rpl == 2 && pl.mix_nfull > 0) {
                 // mixed tiling (shipped geometry only, see prox_plan): the 128-row grid has mix_nfi tile rows
@@ -1071,6 +1085,12 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
                                pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj);                         \
     }
+            if (esub_wanted && !pl.esub_off && spec == 1 && !redo && !pl.pipe && pl.rpl == 1 && pl.cj == 4 && pl.nw == 8 && pl.minw == 4 && g_fused.fast) {
+                launched = true;
+                hipLaunchKernelGGL((chambolle_fused1_kernel<4, 8, 4, true, true>), fgrid, dim3(64 * 8), 0, ctx->stream, g, pl.pbuf,
+                                   pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, redo, f_out, write_f,
+                                   pl.counters, kflags, sj);
+            } else
             SBTV_FUSED1_CASE(4, 8, 4)
 #ifdef SBTV_LAB
             SBTV_FUSED1_CASE(4, 8, 6)

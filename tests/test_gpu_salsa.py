@@ -367,3 +367,28 @@ def test_salsa_1024_batch_images_stop_at_different_iterations_equal_their_single
         assert ref["n_outer"] == n[b]
         np.testing.assert_allclose(one[3], ref["objective"], rtol=1e-9)
         assert np.max(np.abs(one[0] - ref["x"])) < 1e-6
+
+
+def test_long_solve_keeps_its_optimistic_launches(ctx, man512):
+    """Optimistic Chambolle launches sum their error terms over a subset of the pixels (a lower bound that proves the stop
+    rule cannot have fired).  Far beyond convergence the warm-started prox errors sink towards the tolerance; the loop then
+    goes back to the full sums (ProxPlan::esub_off) instead of letting the looser bound send the whole solve down the exact
+    path: the device time per iteration of a 2500-iteration solve stays that of a 300-iteration one (the exact launches
+    cost about twice as much at this size)."""
+    import sbtv
+    import sbtv_oracle as o
+    rng = np.random.default_rng(1)
+    st = o.demo_setup("gaussian", man512, rng.standard_normal(man512.shape), evMax=1.0, BSNR=30.0, true_params=(0.4, 0.3))
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3), ctx=ctx)
+    yd, xd = sbtv.to_device(st["y"]), sbtv.to_device(man512)
+    mu, tau = 0.003, 0.03 * st["sigma"] ** 2
+
+    def per_iteration_ms(K):
+        best = 1e9
+        for _ in range(2):
+            sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0, "MAXITERA", K,
+                          "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+            best = min(best, ctx.last_timing()["loop_ms"] / K)
+        return best
+    short, long_ = per_iteration_ms(300), per_iteration_ms(2500)
+    assert long_ < 1.35 * short, (short, long_)
