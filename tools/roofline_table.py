@@ -11,6 +11,8 @@ tag = sys.argv[1]
 P = 2048 * 2048
 MODEL = [   # kernel prefix, what moves, bytes per pixel
     ("chambolle_fused_kernel<4, 8, 4, true>", "read g,px,py + write px,py once per 5-iteration launch (+ f on every 2nd): 44 B/px", 44),
+    # round 3, last step: the optimistic launches of the loop sum their error over a subset of the pixels (template ESUB)
+    ("chambolle_fused_kernel<4, 8, 4, true, false, true>", "read g,px,py + write px,py once per 5-iteration launch (+ f on every 2nd): 44 B/px", 44),
     ("cols_fwd_wave_kernel<10, 16>", "read u, bu; write S: 24 B/px", 24),
     ("rows_pipe_kernel<11, 4>", "read S, H, Y; write S: 32 B/px", 32),
     ("cols_inv_wave_kernel<10, 16, 3>", "read S, u, bu, true; write x, bu, g: 56 B/px", 56),
@@ -29,7 +31,8 @@ print("Peak 8 TB/s HBM; fp64 vector peak 39.3 T lane-instructions/s.\n")
 print("| kernel | what moves (model) | model MB | avg µs | model TB/s (frac of 8) | PMC MB | PMC TB/s (frac of 8) | PMC / model | VALU issue (frac of 39.3 T/s) | SQ_WAIT_ANY / wave-cycles |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for name, what, bpp in MODEL:
-    key = next((k for k in stats if k.startswith(name) and "empty" not in k), None)
+    key = next((k for k in stats if k.startswith("void sbtv::" + name + "(") or k.startswith(name + "(") or k == name), None) or \
+        next((k for k in stats if k.startswith(name) and "empty" not in k and not k[len(name):].startswith(",")), None)
     if key is None or name not in pmc["kernels"]:
         continue                      # (this build does not launch that variant)
     us = float(stats[key][2])
