@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""SALSA wall time per solve at 2048^2 and 512^2: a converging solve and fixed-length ones (see tools/README.md)."""
 import os, sys, time
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "semi-blind-image-deblurring-problems-with-tv_amd"))
 import bench, numpy as np, torch, sbtv
 ctx = sbtv.Context(0)
