@@ -579,7 +579,11 @@ def main():
             "config": {"workload": "SALSA_v2 TV deblur (TViters=10, mu=theta/10, tau=theta*sigma^2, theta=0.03), "
                                    "one 2048x2048 image per GPU (man.png tiled 4x4), Gaussian PSF 7x7 w=(0.4,0.3), "
                                    "BSNR 30 dB; independent images shard across GPUs",
-                       "image": [SIZE, SIZE], "images_per_gpu": 1, "parallelism": f"images x{world}"},
+                       "image": [SIZE, SIZE], "images_per_gpu": 1, "parallelism": f"images x{world}",
+                       # every iteration of the TV prox runs; what its optimistic launches shorten is the error SUM the stop
+                       # rule is checked with afterwards (a lower bound over a subset of the pixels proves "did not fire";
+                       # otherwise the solve repeats exactly): profiles/r03_chambolle_errsubset.md, SBTV_ERR_SUBSET=0 = full sums
+                       "prox_stop_rule": "exact (chambolle_prox_TV_stop.m:131), checked after the launches on lower-bound step sums"},
             "final_psnr_db": final_psnr, "outer_iterations_to_tol_1e-5": n_conv,
             # rank 0 solves the problem of the committed fixture (seed 1): the PSNR half of the metric, checked
             "psnr_matches_fixture": fixture_check("salsa2048", final_psnr, n_conv),
