@@ -123,6 +123,10 @@ struct sbtv_ctx {
     double timing[4] = {0, 0, 0, 0};
     sbtv::HostStats hstat;
     std::map<std::string, sbtv::DevBuf> ws;   // named device workspaces (grow-only)
+    // what the tap spectrum in workspace "salsa.H" was built from (sbtv_SALSA_v2 keeps it across calls with the same taps)
+    std::vector<double> salsa_h_taps;
+    long long salsa_h_dims[6] = {0, 0, 0, 0, 0, 0};
+    const void *salsa_h_ptr = nullptr;
     std::map<int, double2 *> twiddles;         // n -> exp(-2 pi i k / n), k < n
     std::map<int, double2 *> any_axes;         // n -> Bluestein tables of the arbitrary-size path (fft_any.inc)
     bool any_attr_done = false;                // its kernel's dynamic-LDS limit has been raised on this context's device

@@ -392,3 +392,29 @@ def test_long_solve_keeps_its_optimistic_launches(ctx, man512):
         return best
     short, long_ = per_iteration_ms(300), per_iteration_ms(2500)
     assert long_ < 1.35 * short, (short, long_)
+
+
+def test_tap_spectrum_kept_across_calls_only_for_the_same_taps(cman256):
+    """sbtv_SALSA_v2 keeps the tap spectrum of its previous call when taps and plan are the same.  Taps A, taps B, taps A
+    again on ONE context (and a different image size in between) against a fresh context per solve: same bits."""
+    import sbtv
+    import sbtv_oracle as o
+    rng = np.random.default_rng(7)
+    st = o.demo_setup("gaussian", cman256, rng.standard_normal(cman256.shape), evMax=1.0, BSNR=30.0, true_params=(0.4, 0.3))
+    small = cman256[:128, :192].copy()
+    ys = st["y"][:128, :192].copy()
+    psfs = [sbtv.Gaussian_psf(7, 0.4, 0.3), sbtv.Gaussian_psf(7, 0.6, 0.2)]
+    mu, tau = 0.003, 0.03 * st["sigma"] ** 2
+
+    def solve(ctx, psf, y, x):
+        A = sbtv.BlurOperator(psf, ctx=ctx)
+        return sbtv.SALSA_v2(y, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", x, "ToleranceA", 1e-9, "MAXITERA", 6,
+                             "TVINITIALIZATION", 1, "TViters", 5, ctx=ctx)
+    one = sbtv.Context(0)
+    seq = [(psfs[0], st["y"], cman256), (psfs[0], st["y"], cman256), (psfs[1], st["y"], cman256), (psfs[0], ys, small),
+           (psfs[0], st["y"], cman256), (psfs[1], st["y"], cman256)]
+    for psf, y, x in seq:
+        got = solve(one, psf, y, x)
+        ref = solve(sbtv.Context(0), psf, y, x)
+        np.testing.assert_array_equal(np.asarray(got[0]), np.asarray(ref[0]))
+        np.testing.assert_array_equal(np.asarray(got[3]), np.asarray(ref[3]))
