@@ -272,6 +272,12 @@ typedef struct sbtv_sapg_opts {
     int    chain_offset;      /* index of this call's first chain among ALL chains: chain b draws the
                                  Philox stream chain_offset + b, so chains spread over several processes
                                  (sbtv.dist.split_chains) never repeat a stream                     */
+    int    iter_offset;       /* resume (no counterpart in the reference; SURVEY.md section 5 checkpoint / resume): SAPG
+                                 iteration ii of this call is iteration ii + iter_offset of the chain, i.e. its step is
+                                 delta(ii + iter_offset).  Continue a chain of S samples with x0 = its last sample,
+                                 th_init / p_init / sigma2_init = its last values, warmup = 0, iter_offset = S - 1.  The
+                                 Philox steps of a call always count from 0: give a resumed segment its own seed.
+                                 0 = the reference's loop.                                          */
 } sbtv_sapg_opts;
 
 /*   y: M*N*batch;  x0: start images (NULL -> y, SAPG_algorithm_Guassian.m:10-12)

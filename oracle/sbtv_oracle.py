@@ -780,7 +780,7 @@ def demo_setup(kind, x, noise, evMax, BSNR=30.0, true_params=None, th_init=0.01)
 
 
 def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init=None, fix=None,
-                   fix_sigma=False, c=None):
+                   fix_sigma=False, c=None, X0=None, sigma_init=None, iter_offset=0, keep_X=()):
     """SAPG/SAPG_algorithm_Guassian.m:7-308, SAPG_algorithm_moffat.m:7-297,
     SAPG_algorithm_laplace.m:7-268 (one body; the three files differ only in
     the number of PSF parameters and the step-scale constants).
@@ -788,7 +788,12 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
     `randn(shape)` is called once per MYULA step, warm-up first (the MATLAB
     stream cannot be reproduced: parity is per-step with injected noise).
     Every closure recomputes A(x) exactly like the reference (24 FFTs per
-    iteration for two-parameter PSFs, 18 for Laplace)."""
+    iteration for two-parameter PSFs, 18 for Laplace).
+
+    X0: the reference's op.X0 (start image, default y; SAPG_algorithm_Guassian.m:10-12).  sigma_init overrides the
+    demo's (sigma_min + sigma_max) / 2.  Not in the reference (test infrastructure for re-anchored segments of a long
+    chain, include/sbtv.h `iter_offset`): iter_offset shifts the step, delta(ii + iter_offset); keep_X = 1-based
+    iteration numbers whose sample X is returned in `X_at` (iteration 1 = the state the SAPG loop starts from)."""
     kind = setup["kind"]
     d = DEMO[kind]
     model = setup["model"]
@@ -805,7 +810,8 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
     p_true = setup["p_true"]
     min_sigma = min(setup["sigma_min"], setup["sigma_max"])
     max_sigma = max(setup["sigma_min"], setup["sigma_max"])
-    sigma_init = setup["sigma"] ** 2 if fix_sigma else setup["sigma_init"]
+    if sigma_init is None:
+        sigma_init = setup["sigma"] ** 2 if fix_sigma else setup["sigma_init"]
 
     A, AT = model.A, model.AT
     f = lambda x, p, s2: float(np.linalg.norm(y - A(x, *p), "fro")) ** 2 / (2 * s2)
@@ -814,10 +820,11 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
     gradF_sigma = lambda x, p, s2: float(np.linalg.norm(y - A(x, *p), "fro")) ** 2 / (2 * s2 ** 2) - dimX / (2 * s2)
     proxG = lambda x, theta: chambolle_prox_TV_stop(x, lam=lamb * theta, maxiter=chambolleit)[0]
     logPi = lambda x, theta, p, s2: -f(x, p, s2) - theta * TVnorm(x)
-    delta = lambda i: setup["d_scale"] * ((i ** (-setup["d_exp"])) / dimX)
+    delta = lambda i: setup["d_scale"] * (((i + iter_offset) ** (-setup["d_exp"])) / dimX)
+    X_at = {}
 
     # ---- warm-up (SAPG_algorithm_Guassian.m:66-93)
-    X = y.copy()
+    X = y.copy() if X0 is None else np.array(X0, dtype=np.float64)
     logPiTrace_WU = np.zeros(max(warmup, 1))
     if warmup > 0:
         prox = proxG(X, setup["th_init"])
@@ -836,6 +843,8 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
     grads = np.zeros((npar + 2, samples))
     logPiTraceX[0] = logPi(X, thetas[0], tuple(ps[:, 0]), sigmas[0])
     prox = proxG(X, thetas[0])
+    if 1 in keep_X:
+        X_at[1] = X.copy()
     for ii in range(2, samples + 1):
         i0 = ii - 1          # 0-based slot of iteration ii
         pm = tuple(ps[:, i0 - 1])
@@ -856,11 +865,13 @@ def SAPG_algorithm(setup, samples, warmup, burnIn, randn, chambolleit=25, p_init
         grads[npar + 1, i0] = G_s
         logPiTraceX[i0] = logPi(X, thetas[i0 - 1], pm, sigmas[i0 - 1])
         gX[i0 - 1] = TVnorm(X)
+        if ii in keep_X:
+            X_at[ii] = X.copy()
     b0 = int(burnIn) - 1
     return dict(theta_EB=float(np.mean(thetas[b0:])), p_EB=[float(np.mean(ps[q, b0:])) for q in range(npar)],
                 sigma_EB=float(np.mean(sigmas[b0:])), thetas=thetas, ps=ps, sigmas=sigmas,
                 logPiTraceX=logPiTraceX, logPiTrace_WU=logPiTrace_WU, gXTrace=gX, grads=grads,
-                Xlast_sample=X, prox_last=prox, err_psf=err_psf_trace(kind, ps, p_true, model.psf_size))
+                Xlast_sample=X, prox_last=prox, err_psf=err_psf_trace(kind, ps, p_true, model.psf_size), X_at=X_at)
 
 
 def SAPG_algorithm_shared(setup, chains, samples, warmup, burnIn, randn, chambolleit=25, p_init=None, fix=None,

@@ -840,6 +840,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: need samples >= 2, 1 <= burnIn <= samples");
     if (op->chambolleit <= 0) return fail(ctx, SBTV_ERR_MAXITER, "SAPG_algorithm: chambolleit must be positive");
     if (op->chain_offset < 0) return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: chain_offset must be >= 0");
+    if (op->iter_offset < 0) return fail(ctx, SBTV_ERR_BADARG, "SAPG_algorithm: iter_offset must be >= 0");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     const int npar = (op->kind == SBTV_PSF_LAPLACE) ? 1 : 2;
     const int shared = op->share_gradients ? 1 : 0;
@@ -1268,7 +1269,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         // constants and initial chain state
         {
             std::vector<double> dl((size_t)samples + 1, 0.0);
-            for (int ii = 2; ii <= samples; ++ii) dl[ii] = op->d_scale * (pow((double)ii, -op->d_exp) / dimX);      // :55
+            for (int ii = 2; ii <= samples; ++ii) dl[ii] = op->d_scale * (pow((double)ii + op->iter_offset, -op->d_exp) / dimX);      // :55
             std::vector<SapgChain> ch(batch);
             for (int b = 0; b < batch; ++b) {
                 ch[b] = SapgChain{theta[b], p0[b], p1[b], sig2[b], 0.0, 0.0, 0.0, 0.0};
@@ -1457,7 +1458,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         const int i0 = ii - 1;
         const int rc_dev = iterate_device(ii);
         if (rc_dev != 0 && !(shared && reduce_fn)) return rc_dev;
-        const double delta = op->d_scale * (pow((double)ii, -op->d_exp) / dimX);              // :55
+        const double delta = op->d_scale * (pow((double)ii + op->iter_offset, -op->d_exp) / dimX);     // :55
         // per-chain gradients
         std::vector<double> Gt(batch), Gp0(batch), Gp1(batch), Gs(batch);
         for (int b = 0; b < batch && rc_dev == 0; ++b) {

@@ -36,6 +36,7 @@ o.phi = getf(op,'phi',0);
 o.sigma2_true = op.sigma^2; o.sigma2_init = op.sigma_init; o.sigma2_min = op.sigma_min; o.sigma2_max = op.sigma_max;
 o.d_scale = op.d_scale; o.d_exp = op.d_exp; o.c_theta = c.theta; o.c_sigma = c.sigma;
 o.seed = uint64(getf(op,'seed',1)); o.chain_offset = int32(getf(op,'chain_offset',0));
+o.iter_offset = int32(getf(op,'iter_offset',0));
 S = double(o.samples); W = max(double(o.warmup),1);
 pth = libpointer('doublePtr', zeros(1,S)); psg = libpointer('doublePtr', zeros(1,S));
 pps = libpointer('doublePtr', zeros(S,2)); plp = libpointer('doublePtr', zeros(1,S));

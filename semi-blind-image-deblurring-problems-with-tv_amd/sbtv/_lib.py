@@ -51,7 +51,7 @@ class sbtv_sapg_opts(C.Structure):
                 ("sigma2_true", C.c_double),
                 ("d_scale", C.c_double), ("d_exp", C.c_double),
                 ("c_theta", C.c_double), ("c_p", C.c_double * 2), ("c_sigma", C.c_double),
-                ("seed", C.c_ulonglong), ("chain_offset", C.c_int)]
+                ("seed", C.c_ulonglong), ("chain_offset", C.c_int), ("iter_offset", C.c_int)]
 
 
 def vptr(a):

@@ -121,6 +121,7 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
     o.c_sigma = float(c["sigma"])
     o.seed = int(_get(op, "seed", 1))
     o.chain_offset = int(_get(op, "chain_offset", 0))              # first chain of this process (dist.split_chains)
+    o.iter_offset = int(_get(op, "iter_offset", 0))                # resume: iteration ii of this call steps with delta(ii + offset)
     S, W = o.samples, max(o.warmup, 1)
     nch = B
     thetas = np.zeros((nch, S)); sigmas = np.zeros((nch, S)); ps = np.zeros((nch, 2, S))

@@ -1,0 +1,68 @@
+"""Seeded INPUTS of the long-chain SAPG parity cases (round 4): chains long enough that the projections of
+SAPG_algorithm_Guassian.m:166-194 engage and release, run with the reference's OWN step scales.
+
+Shared by `make_golden_sapg.py` (runs the oracle in the build container -> `sapg_long.npz`), by
+`tests/test_golden_sapg_cpu.py` (the oracle is re-checked against the file on every CPU run) and by
+`tests/test_gpu_sapg_long.py` (rebuilds the same inputs on the GPU box and holds the HIP path against the file).
+
+Step scales (the point of these cases; the full-size fixtures of `large_cases.py` use gentler ones):
+  gaussian  c.theta = 0.01, c.w1 = c.w2 = 10, c.sigma = 1000        run_Gaussian_demo.m:34-39, with fix_w1 = fix_w2 = 0
+            so that both widths are estimated (the demo sets the two flags to 1, :42-43), init 0.5 / 0.3 (:68-69)
+  moffat    0.1, 10, 1e4, 1e4                                        SAPG_algorithm_moffat.m:135-138, init 1 / 10
+  laplace   0.01, 100, 1e4                                           SAPG_algorithm_laplace.m:139-141, init 0.1
+These are the constants of `sbtv_oracle.DEMO`, which the oracle takes when no `c` is passed.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for _p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+FIXTURE = os.path.join(HERE, "sapg_long.npz")
+KINDS = ("gaussian", "moffat", "laplace")
+NAMES = {"gaussian": ("w1", "w2"), "moffat": ("alpha", "beta"), "laplace": ("b",)}
+SIZE = 64
+
+# per-step parity with injected noise: >= 300 samples (review item 1b)
+TRACE = dict(samples=320, warmup=60, burnIn=256)
+# statistical parity of the EB estimates: 8 chains of >= 1500 iterations (review item 1c)
+STAT = dict(samples=1600, warmup=300, burnIn=1280, chains=8)
+
+# free parameters of every family; the Gaussian demo's fix flags are lifted and its free-run initial values used
+FREE = {"gaussian": dict(fix=(False, False), p_init=(0.5, 0.3)), "moffat": dict(fix=None, p_init=None),
+        "laplace": dict(fix=None, p_init=None)}
+
+
+def _oracle():
+    import sbtv_oracle
+    return sbtv_oracle
+
+
+def image(kind):
+    from conftest import synth_image
+    return synth_image(SIZE, SIZE, 21 + KINDS.index(kind))
+
+
+def setup(kind):
+    """Observation model + step sizes (run_*_demo.m:145-184) by the oracle's `demo_setup`, the same bits on both
+    machines (one blur of a 64^2 image)."""
+    o = _oracle()
+    k = KINDS.index(kind)
+    x = image(kind)
+    return o.demo_setup(kind, x, np.random.default_rng(100 + k).standard_normal(x.shape), evMax=0.99)
+
+
+def trace_noise(kind):
+    """[step][M][N] normals of the per-step parity case: warm-up steps first, then one per SAPG iteration."""
+    steps = TRACE["warmup"] - 1 + TRACE["samples"] - 1
+    return np.random.default_rng(200 + KINDS.index(kind)).standard_normal((steps, SIZE, SIZE))
+
+
+def stat_rng(kind, chain):
+    """NumPy stream of oracle chain `chain` of the statistical case (the GPU draws Philox streams instead)."""
+    return np.random.default_rng(3000 + 10 * KINDS.index(kind) + chain)

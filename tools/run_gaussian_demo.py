@@ -3,7 +3,10 @@
 observation model -> evMax -> SAPG (MYULA) estimates of theta, PSF parameters, sigma^2 -> SALSA_v2 MAP image.
 
   python tools/run_gaussian_demo.py [--kind gaussian|moffat|laplace] [--samples 20000 --warmup 15000]
-                                    [--image tests/golden/man_512.npy]
+                                    [--image tests/golden/wheel_512.npy]
+
+The default image is the one the three demos load: images/wheel.png (entry 8 of the directory listing,
+run_Gaussian_demo.m:100,117; run_moffat_demo.m:108,116; run_laplace_demo.m:83,90).
 
 Constants follow run_Gaussian_demo.m:34-85 / run_moffat_demo.m:34-73 / run_laplace_demo.m:34-62
 (SURVEY.md §9.1).  MATLAB's randn('state',1) stream cannot be reproduced: noise comes from NumPy
@@ -32,7 +35,7 @@ DEMO = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="gaussian", choices=list(DEMO))
-    ap.add_argument("--image", default=os.path.join(ROOT, "tests", "golden", "man_512.npy"))
+    ap.add_argument("--image", default=os.path.join(ROOT, "tests", "golden", "wheel_512.npy"))
     ap.add_argument("--samples", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=15000)
     ap.add_argument("--seed", type=int, default=1)
