@@ -82,6 +82,16 @@ const char *sbtv_last_error(const sbtv_ctx *ctx);   /* ctx may be NULL: global m
 /* Use an externally owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
 int         sbtv_ctx_set_stream(sbtv_ctx *ctx, void *hip_stream);
 int         sbtv_ctx_sync(sbtv_ctx *ctx);
+/* Lanes (no counterpart in the reference): a call with batch >= 2 independent items (the images of sbtv_SALSA_v2 /
+ * sbtv_fista_tv / sbtv_CSALSA_v2 / sbtv_CoRAL_v2, the independent chains of sbtv_SAPG_algorithm) is dealt in two
+ * contiguous halves to two internal contexts on the same GPU - own stream, workspaces and host thread each - so that the
+ * launch tails and memory-bound passes of one half run under the Chambolle launches of the other (+15..20 % image-
+ * iterations/s).  Results do not change: a batched call computes image k bit for bit like image k alone.
+ *   mode 0 (default) independent items only;  1 never (one stream);  2 also shared-gradient chains (share_gradients = 1:
+ *   the two halves then exchange their six gradient sums in-stream once per SAPG iteration, results equal to rounding).
+ * The environment variable SBTV_LANES = 0 | 1 | 2 overrides the mode of every context.  With a caller-owned stream
+ * (sbtv_ctx_set_stream) the call first waits for that stream, then runs on the lanes' own streams. */
+int         sbtv_ctx_set_lanes(sbtv_ctx *ctx, int mode);
 /* Operator-call counters: the reference's global `calls` (SALSA/callcounter.m:8-15). */
 int         sbtv_callcounter_get(const sbtv_ctx *ctx, long long *calls);
 int         sbtv_callcounter_reset(sbtv_ctx *ctx);
@@ -346,6 +356,9 @@ int sbtv_MSE(sbtv_ctx *ctx, const double *x_true, const double *x, int M, int N,
  * entry of `devices` (an ordinal may repeat: "virtual shards" on one GPU).  Items are dealt to the shards in
  * contiguous blocks (sbtv_group_shard_of); only min(n, n_items) shards take part in a call.  All pointers are HOST
  * pointers, laid out exactly as for the single-context entry points with batch = n_items.
+ *   sbtv_fista_tv_sharded, sbtv_CSALSA_v2_sharded, sbtv_CoRAL_v2_sharded: independent images, no exchange
+ *                                (SALSA/my_fista.m:5, SALSA/CSALSA_v2.m:160, SALSA/CoRAL_v2.m:2); arguments as for the
+ *                                single-context entry points.
  *   sbtv_SALSA_v2_sharded        independent images: no exchange; image k is computed bit for bit as by sbtv_SALSA_v2.
  *   sbtv_SAPG_algorithm_sharded  op->share_gradients = 0: independent images / chains (chain i draws the Philox stream
  *                                op->chain_offset + i whatever the sharding).  share_gradients = 1: n_items MYULA chains
@@ -372,6 +385,24 @@ int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, in
                                 const sbtv_sapg_opts *op, const double *x0, const double *noise,
                                 double *thetas, double *ps, double *sigmas, double *logpi,
                                 double *logpi_wu, double *gx, double *grads, double *eb, double *x_last);
+int sbtv_fista_tv_sharded(sbtv_group *g, const double *b, int M, int N, int n_items,
+                          const double *taps, int taille, const double *tau, double L,
+                          int prox_iters, int stopcriterion, double tolerance, int maxiters,
+                          int zero_start, const double *true_x, double *x_out,
+                          double *objective, double *mses, int *n_iter);
+int sbtv_CSALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_items,
+                           const double *taps, int taille, const double *mu1, const double *mu2,
+                           const double *sigma, const double *epsilon, double continuationfactor,
+                           const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                           double *x_out, double *objective, double *distance1, double *distance2,
+                           double *criterion, double *times, double *mses,
+                           int *numA, int *numAt, int *n_outer);
+int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_items,
+                          const double *taps, int taille, const double *tau1, const double *tau2,
+                          const double *mu1, const double *mu2, const double *mu_ls, int TViters2,
+                          const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                          double *x_out, double *objective, double *distance, double *times, double *mses,
+                          int *numA, int *numAt, int *n_outer);
 
 /* ---- diagnostics (no counterpart in the reference; SURVEY.md §5 sanitizer / tracing rows) ----
  * sbtv_diag_canary: with SBTV_CANARY=1 in the environment when the context was created, every device workspace of

@@ -951,6 +951,12 @@ int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, cons
             return fail(ctx, SBTV_ERR_MISSING_LS, "(A^T A + mu I)^(-1) must be specified: mu1, mu2 must be > 0");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     { FftPlan chk; SBTV_TRY(fft_plan(ctx, M, N, 1, &chk)); }
+    if (sbtv_group *lg = lanes_group(ctx, batch, false)) {       // independent images: two lanes of this context (group.hip)
+        LaneCall lc(ctx, lg);
+        return lc.done(csalsa_sharded(lg, y, M, N, batch, taps, taille, mu1, mu2, sigma, epsilon, continuationfactor, opts,
+                                      true_x, x_init, x_out, objective, distance1, distance2, criterion, times, mses, numA,
+                                      numAt, n_outer, flags), batch);
+    }
     const size_t P = (size_t)M * N, cnt = P * batch;
     const double *yd = nullptr, *td = nullptr, *xi = nullptr;
     SBTV_TRY(stage_in(ctx, "admm.in.y", y, cnt, flags, &yd));
@@ -997,6 +1003,11 @@ int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
             return fail(ctx, SBTV_ERR_MISSING_LS, "(A^T A + mu I)^(-1) must be specified: mu1, mu2 must be > 0");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     { FftPlan chk; SBTV_TRY(fft_plan(ctx, M, N, 1, &chk)); }
+    if (sbtv_group *lg = lanes_group(ctx, batch, false)) {       // independent images: two lanes of this context (group.hip)
+        LaneCall lc(ctx, lg);
+        return lc.done(coral_sharded(lg, y, M, N, batch, taps, taille, tau1, tau2, mu1, mu2, mu_ls, TViters2, opts, true_x,
+                                     x_init, x_out, objective, distance, times, mses, numA, numAt, n_outer, flags), batch);
+    }
     const size_t P = (size_t)M * N, cnt = P * batch;
     const double *yd = nullptr, *td = nullptr, *xi = nullptr;
     SBTV_TRY(stage_in(ctx, "admm.in.y", y, cnt, flags, &yd));

@@ -253,15 +253,72 @@ int sbtv_SALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
                           const double *tau, const double *mu, const sbtv_salsa_opts *opts, const double *true_x,
                           const double *x_init, double *x_out, double *objective, double *distance, double *times,
                           double *mses, int *numA, int *numAt, int *n_outer) {
+    return salsa_sharded(g, y, M, N, n_items, taps, taille, tau, mu, opts, true_x, x_init, x_out, objective, distance, times,
+                         mses, numA, numAt, n_outer, SBTV_HOST_PTRS);
+}
+
+int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const sbtv_sapg_opts *op,
+                                const double *x0, const double *noise, double *thetas, double *ps, double *sigmas,
+                                double *logpi, double *logpi_wu, double *gx, double *grads, double *eb, double *x_last) {
+    return sapg_sharded(g, y, M, N, n_items, op, x0, noise, thetas, ps, sigmas, logpi, logpi_wu, gx, grads, eb, x_last,
+                        SBTV_HOST_PTRS);
+}
+
+int sbtv_fista_tv_sharded(sbtv_group *g, const double *b, int M, int N, int n_items, const double *taps, int taille,
+                          const double *tau, double L, int prox_iters, int stopcriterion, double tolerance, int maxiters,
+                          int zero_start, const double *true_x, double *x_out, double *objective, double *mses, int *n_iter) {
+    return fista_sharded(g, b, M, N, n_items, taps, taille, tau, L, prox_iters, stopcriterion, tolerance, maxiters, zero_start,
+                         true_x, x_out, objective, mses, n_iter, SBTV_HOST_PTRS);
+}
+
+int sbtv_CSALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                           const double *mu1, const double *mu2, const double *sigma, const double *epsilon,
+                           double continuationfactor, const sbtv_salsa_opts *opts, const double *true_x,
+                           const double *x_init, double *x_out, double *objective, double *distance1, double *distance2,
+                           double *criterion, double *times, double *mses, int *numA, int *numAt, int *n_outer) {
+    return csalsa_sharded(g, y, M, N, n_items, taps, taille, mu1, mu2, sigma, epsilon, continuationfactor, opts, true_x, x_init,
+                          x_out, objective, distance1, distance2, criterion, times, mses, numA, numAt, n_outer, SBTV_HOST_PTRS);
+}
+
+int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                          const double *tau1, const double *tau2, const double *mu1, const double *mu2, const double *mu_ls,
+                          int TViters2, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                          double *x_out, double *objective, double *distance, double *times, double *mses, int *numA,
+                          int *numAt, int *n_outer) {
+    return coral_sharded(g, y, M, N, n_items, taps, taille, tau1, tau2, mu1, mu2, mu_ls, TViters2, opts, true_x, x_init, x_out,
+                         objective, distance, times, mses, numA, numAt, n_outer, SBTV_HOST_PTRS);
+}
+
+int sbtv_ctx_set_lanes(sbtv_ctx *ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return SBTV_ERR_BADARG;
+    ctx->lanes_mode = mode;
+    return 0;
+}
+
+}  // extern "C"
+
+// ================================ the sharded drivers (host or device pointers) ================================
+namespace sbtv {
+
+static inline int active_shards(sbtv_group *g, int n_items) {
+    const int ns = std::min((int)g->ctxs.size(), n_items);
+    g->active = ns;
+    g->rv.reset(ns);
+    return ns;
+}
+template <class T>
+static inline T *off(T *p, size_t o) { return p ? p + o : p; }
+
+int salsa_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                  const double *tau, const double *mu, const sbtv_salsa_opts *opts, const double *true_x,
+                  const double *x_init, double *x_out, double *objective, double *distance, double *times, double *mses,
+                  int *numA, int *numAt, int *n_outer, int flags) {
     if (!g) return SBTV_ERR_BADARG;
     if (!y || !tau || !mu || !opts || n_items < 1 || M < 2 || N < 2)
         return gfail(g, SBTV_ERR_BADARG, "SALSA_v2_sharded: missing required argument");
     if (!taps) return gfail(g, SBTV_ERR_MISSING_AT, "The function handle for transpose of A is missing");
-    const int ns = std::min((int)g->ctxs.size(), n_items);
-    g->active = ns;
-    g->rv.reset(ns);
+    const int ns = active_shards(g, n_items);
     const size_t P = (size_t)M * N, t2 = (size_t)taille * taille, K = (size_t)(opts->maxiter > 0 ? opts->maxiter : 0);
-    auto off = [](auto *p, size_t o) { return p ? p + o : p; };
     return run_shards(g, ns, [&](int r) -> int {
         int lo, hi;
         block_of(n_items, ns, r, &lo, &hi);
@@ -269,23 +326,22 @@ int sbtv_SALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
         return sbtv_SALSA_v2(g->ctxs[r], y + b * P, M, N, hi - lo, taps + b * t2, taille, tau + b, mu + b, opts,
                              off(true_x, b * P), off(x_init, b * P), off(x_out, b * P), off(objective, b * (K + 1)),
                              off(distance, b * K), off(times, b * (K + 1)), off(mses, b * (K + 1)), off(numA, b),
-                             off(numAt, b), off(n_outer, b), SBTV_HOST_PTRS);
+                             off(numAt, b), off(n_outer, b), flags);
     });
 }
 
-int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const sbtv_sapg_opts *op,
-                                const double *x0, const double *noise, double *thetas, double *ps, double *sigmas,
-                                double *logpi, double *logpi_wu, double *gx, double *grads, double *eb, double *x_last) {
+int sapg_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const sbtv_sapg_opts *op, const double *x0,
+                 const double *noise, double *thetas, double *ps, double *sigmas, double *logpi, double *logpi_wu,
+                 double *gx, double *grads, double *eb, double *x_last, int flags) {
     if (!g) return SBTV_ERR_BADARG;
     if (!y || !op || n_items < 1 || M < 2 || N < 2) return gfail(g, SBTV_ERR_BADARG, "SAPG_algorithm_sharded: missing required argument");
-    const int ns = std::min((int)g->ctxs.size(), n_items);
-    g->active = ns;
-    g->rv.reset(ns);
+    const int ns = active_shards(g, n_items);
+    if (noise && ns > 1 && (flags & SBTV_DEVICE_PTRS))
+        return gfail(g, SBTV_ERR_BADARG, "SAPG_algorithm_sharded: injected noise must be a host array (it is re-packed per shard)");
     for (auto &it : g->iter) it = 0;
     const bool shared = op->share_gradients != 0;
     const size_t P = (size_t)M * N, S = (size_t)(op->samples > 0 ? op->samples : 0), W = (size_t)(op->warmup > 0 ? op->warmup : 1);
     const size_t steps = (size_t)(op->warmup > 1 ? op->warmup - 1 : 0) + (S > 0 ? S - 1 : 0);
-    auto off = [](auto *p, size_t o) { return p ? p + o : p; };
     std::vector<ShardUser> users(ns);
     return run_shards(g, ns, [&](int r) -> int {
         int lo, hi;
@@ -313,8 +369,129 @@ int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, in
                                    off(logpi_wu, b * W), off(gx, b * S), off(grads, b * 4 * S), off(eb, b * 4),
                                    off(x_last, b * P),
                                    coll ? reinterpret_cast<sbtv_allreduce_fn>(&group_allreduce) : nullptr,
-                                   coll ? &users[r] : nullptr, SBTV_HOST_PTRS | (coll ? SBTV_REDUCE_DEVICE : 0));
+                                   coll ? &users[r] : nullptr, flags | (coll ? SBTV_REDUCE_DEVICE : 0));
     });
 }
 
-}  // extern "C"
+// my_fista over independent images (SALSA/my_fista.m:5): no exchange
+int fista_sharded(sbtv_group *g, const double *bimg, int M, int N, int n_items, const double *taps, int taille,
+                  const double *tau, double L, int prox_iters, int stopcriterion, double tolerance, int maxiters,
+                  int zero_start, const double *true_x, double *x_out, double *objective, double *mses, int *n_iter,
+                  int flags) {
+    if (!g) return SBTV_ERR_BADARG;
+    if (!bimg || !taps || !tau || !true_x || n_items < 1 || maxiters < 1 || M < 2 || N < 2)
+        return gfail(g, SBTV_ERR_BADARG, "fista_tv_sharded: bad arguments (b, taps, tau, true are required)");
+    const int ns = active_shards(g, n_items);
+    const size_t P = (size_t)M * N, t2 = (size_t)taille * taille, K = (size_t)maxiters;
+    return run_shards(g, ns, [&](int r) -> int {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        const size_t b = (size_t)lo;
+        return sbtv_fista_tv(g->ctxs[r], bimg + b * P, M, N, hi - lo, taps + b * t2, taille, tau + b, L, prox_iters,
+                             stopcriterion, tolerance, maxiters, zero_start, true_x + b * P, off(x_out, b * P),
+                             off(objective, b * K), off(mses, b * K), off(n_iter, b), flags);
+    });
+}
+
+// C-SALSA over independent images (SALSA/CSALSA_v2.m:160): no exchange; every trace row has maxiter entries
+int csalsa_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                   const double *mu1, const double *mu2, const double *sigma, const double *epsilon,
+                   double continuationfactor, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                   double *x_out, double *objective, double *distance1, double *distance2, double *criterion,
+                   double *times, double *mses, int *numA, int *numAt, int *n_outer, int flags) {
+    if (!g) return SBTV_ERR_BADARG;
+    if (!y || !taps || !mu1 || !mu2 || !sigma || !opts || n_items < 1 || M < 2 || N < 2)
+        return gfail(g, SBTV_ERR_BADARG, "CSALSA_v2_sharded: missing required argument");
+    const int ns = active_shards(g, n_items);
+    const size_t P = (size_t)M * N, t2 = (size_t)taille * taille, K = (size_t)(opts->maxiter > 0 ? opts->maxiter : 0);
+    return run_shards(g, ns, [&](int r) -> int {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        const size_t b = (size_t)lo;
+        return sbtv_CSALSA_v2(g->ctxs[r], y + b * P, M, N, hi - lo, taps + b * t2, taille, mu1 + b, mu2 + b, sigma + b,
+                              off(epsilon, b), continuationfactor, opts, off(true_x, b * P), off(x_init, b * P),
+                              off(x_out, b * P), off(objective, b * K), off(distance1, b * K), off(distance2, b * K),
+                              off(criterion, b * K), off(times, b * K), off(mses, b * K), off(numA, b), off(numAt, b),
+                              off(n_outer, b), flags);
+    });
+}
+
+// CoRAL over independent images (SALSA/CoRAL_v2.m:2): no exchange
+int coral_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                  const double *tau1, const double *tau2, const double *mu1, const double *mu2, const double *mu_ls,
+                  int TViters2, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init, double *x_out,
+                  double *objective, double *distance, double *times, double *mses, int *numA, int *numAt, int *n_outer,
+                  int flags) {
+    if (!g) return SBTV_ERR_BADARG;
+    if (!y || !taps || !tau1 || !tau2 || !mu1 || !mu2 || !opts || n_items < 1 || M < 2 || N < 2)
+        return gfail(g, SBTV_ERR_BADARG, "CoRAL_v2_sharded: missing required argument");
+    const int ns = active_shards(g, n_items);
+    const size_t P = (size_t)M * N, t2 = (size_t)taille * taille, K = (size_t)(opts->maxiter > 0 ? opts->maxiter : 0);
+    return run_shards(g, ns, [&](int r) -> int {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        const size_t b = (size_t)lo;
+        return sbtv_CoRAL_v2(g->ctxs[r], y + b * P, M, N, hi - lo, taps + b * t2, taille, tau1 + b, tau2 + b, mu1 + b,
+                             mu2 + b, off(mu_ls, b), TViters2, opts, off(true_x, b * P), off(x_init, b * P),
+                             off(x_out, b * P), off(objective, b * (K + 1)), off(distance, b * K * 2),
+                             off(times, b * (K + 1)), off(mses, b * (K + 1)), off(numA, b), off(numAt, b),
+                             off(n_outer, b), flags);
+    });
+}
+
+// ================================ lanes: two streams behind ONE context ================================
+// Evidence (BENCH_r03.json): four 2048^2 images in one context, one stream: 4 500 image-iterations/s; the same four as
+// 2 + 2 on two streams of the same GPU: 5 375.  Independent items by construction (SAPG_algorithm_moffat.m:143-173:
+// chains; the images of a batch), so the split needs no exchange; shared-gradient chains use the in-process exchange
+// above (lanes_mode 2 only: one exchange per SAPG iteration couples the two streams).
+::sbtv_group *lanes_group(sbtv_ctx *ctx, int n_items, bool shared) {
+    static const int env_mode = [] {
+        const char *e = getenv("SBTV_LANES");
+        return (e && e[0] >= '0' && e[0] <= '2' && e[1] == '\0') ? e[0] - '0' : -1;
+    }();
+    if (!ctx || ctx->is_lane || n_items < 2) return nullptr;
+    const int mode = env_mode >= 0 ? env_mode : ctx->lanes_mode;
+    if (mode == 1 || (shared && mode != 2)) return nullptr;
+    if (!ctx->lanes) {
+        // two lanes; SBTV_LANE_COUNT = 2..8 for experiments (profiles/r04_lanes.md: what more lanes buy)
+        static const int n_lanes = [] {
+            const char *e = getenv("SBTV_LANE_COUNT");
+            const int v = e ? atoi(e) : 2;
+            return v >= 2 && v <= 8 ? v : 2;
+        }();
+        int dev[8];
+        for (int &d : dev) d = ctx->device;
+        sbtv_group *g = nullptr;
+        if (sbtv_group_create(dev, n_lanes, &g) != 0) return nullptr;       // no lanes: the call runs on ctx itself
+        for (sbtv_ctx *c : g->ctxs) c->is_lane = true;
+        ctx->lanes = g;
+    }
+    return ctx->lanes;
+}
+
+LaneCall::LaneCall(sbtv_ctx *c, ::sbtv_group *grp) : ctx(c), g(grp) {
+    // a stream the caller gave us (sbtv_ctx_set_stream) may still hold the work that produces the inputs
+    if (!ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    for (size_t r = 0; r < g->ctxs.size() && r < 8; ++r) calls0[r] = g->ctxs[r]->calls;
+}
+
+int LaneCall::done(int rc, int n_items) {
+    const int ns = std::min((int)g->ctxs.size(), n_items);
+    double t[4] = {0, 0, 0, 0};
+    for (int r = 0; r < ns; ++r) {
+        const sbtv_ctx *c = g->ctxs[r];
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        ctx->calls += c->calls - calls0[r];                  // callcounter.m: one count per operator application and image
+        t[0] = std::max(t[0], c->timing[0]);                 // device time of the loop: the longer lane
+        t[1] = std::max(t[1], c->timing[1]);
+        t[2] += c->timing[2] * (double)(hi - lo) / n_items;  // Chambolle iterations, image-averaged
+        t[3] += c->timing[3];
+    }
+    for (int i = 0; i < 4; ++i) ctx->timing[i] = t[i];
+    ctx->hstat = g->ctxs[0]->hstat;
+    if (rc != 0) return fail(ctx, rc, g->err);
+    return 0;
+}
+
+}  // namespace sbtv

@@ -92,6 +92,12 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     for (int b = 0; b < batch; ++b)
         if (!(mu[b] > 0.0)) return fail(ctx, SBTV_ERR_MISSING_LS, "(A^T A + mu I)^(-1) must be specified: mu must be > 0");
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    // a batch: the images are independent (each stops by its own rule) -> two lanes of this context, group.hip
+    if (sbtv_group *lg = lanes_group(ctx, batch, false)) {
+        LaneCall lc(ctx, lg);
+        return lc.done(salsa_sharded(lg, y, M, N, batch, taps, taille, tau, mu, opts, true_x, x_init, x_out, objective,
+                                     distance, times, mses, numA, numAt, n_outer, flags), batch);
+    }
     FftPlan fp;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
     ProxPlan pp;

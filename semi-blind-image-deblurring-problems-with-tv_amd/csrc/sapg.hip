@@ -434,6 +434,11 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
     SBTV_HIP(ctx, hipSetDevice(ctx->device));
     if (((size_t)M * N) & 1)
         return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
+    if (sbtv_group *lg = lanes_group(ctx, batch, false)) {       // independent images: two lanes of this context (group.hip)
+        LaneCall lc(ctx, lg);
+        return lc.done(fista_sharded(lg, bimg, M, N, batch, taps, taille, tau, L, prox_iters, stopcriterion, tolerance, maxiters,
+                                     zero_start, true_x, x_out, objective, mses, n_iter, flags), batch);
+    }
     FftPlan fp;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
     ProxPlan pp;
@@ -847,6 +852,16 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
     const int nspec = shared ? 1 : batch;              // spectra sets (H, D1, D2, Y)
     if (((size_t)M * N) & 1)
         return fail(ctx, SBTV_ERR_SIZE, "this entry point needs an even number of pixels (its element-wise passes move two per lane)");
+    // independent chains (SAPG_algorithm_moffat.m:143-173: every chain has its own state) -> two lanes of this context;
+    // shared-gradient chains only in lanes_mode 2 (their per-iteration exchange couples the two streams).  Not when the
+    // caller reduces across processes itself, forces the host loop, or injects device-resident noise (re-packed per lane).
+    if (!reduce_fn && !(flags & (SBTV_SAPG_HOST_LOOP | SBTV_REDUCE_DEVICE)) && !(noise && (flags & SBTV_DEVICE_PTRS))) {
+        if (sbtv_group *lg = lanes_group(ctx, batch, shared != 0)) {
+            LaneCall lc(ctx, lg);
+            return lc.done(sapg_sharded(lg, y, M, N, batch, op, x0, noise, thetas, ps, sigmas, logpi, logpi_wu, gx, grads, eb,
+                                        x_last, flags), batch);
+        }
+    }
     FftPlan fp, fps;
     SBTV_TRY(fft_plan(ctx, M, N, batch, &fp));
     SBTV_TRY(fft_plan(ctx, M, N, nspec, &fps));

@@ -137,6 +137,13 @@ struct sbtv_ctx {
     int cu_count = 256;
     // SBTV_CANARY=1 (read when the context is created): every workspace gets a guard band on both sides,
     // verified at the end of each C-ABI call (canary_epilogue)
+    // Lanes: a batch of independent items (images, chains) is dealt to two internal contexts on this device, one host
+    // thread and one stream each, so that the launch tails and the memory-bound passes of one half run under the
+    // issue-bound Chambolle launches of the other (csrc/group.hip, `lanes_group`).  Image k is computed bit for bit as
+    // without lanes (a batched call computes every image like that image alone).
+    struct sbtv_group *lanes = nullptr;        // created on first use, destroyed with the context
+    int lanes_mode = 0;                        // 0: independent items only (default), 1: never, 2: shared-gradient chains too
+    bool is_lane = false;                      // this context IS a lane: never split again
     bool canary = false;
     bool canary_dirty = true;                  // the descriptor table below is stale
     void *canary_desc = nullptr;               // device: {lo guard, hi guard} per workspace
@@ -252,6 +259,40 @@ struct ProxArm {
     double tol, tau;
     const int *frozen;          // optional per-image flag: armed as done (FISTA batches)
 };
+
+// ---- lanes (group.hip): the two-stream split of a batch inside ONE context
+// the internal group to deal `n_items` independent items (shared = chains that exchange their gradients) to, or nullptr
+// when the call runs on ctx itself (one item, lanes switched off, ctx is a lane, or the group cannot be created)
+::sbtv_group *lanes_group(sbtv_ctx *ctx, int n_items, bool shared);
+// brackets a call that was handed to the lanes: books calls / timings / the error message on the parent context
+struct LaneCall {
+    sbtv_ctx *ctx;
+    ::sbtv_group *g;
+    long long calls0[8];
+    LaneCall(sbtv_ctx *c, ::sbtv_group *grp);
+    int done(int rc, int n_items);
+};
+int salsa_sharded(::sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                  const double *tau, const double *mu, const sbtv_salsa_opts *opts, const double *true_x,
+                  const double *x_init, double *x_out, double *objective, double *distance, double *times, double *mses,
+                  int *numA, int *numAt, int *n_outer, int flags);
+int sapg_sharded(::sbtv_group *g, const double *y, int M, int N, int n_items, const sbtv_sapg_opts *op,
+                 const double *x0, const double *noise, double *thetas, double *ps, double *sigmas, double *logpi,
+                 double *logpi_wu, double *gx, double *grads, double *eb, double *x_last, int flags);
+int fista_sharded(::sbtv_group *g, const double *b, int M, int N, int n_items, const double *taps, int taille,
+                  const double *tau, double L, int prox_iters, int stopcriterion, double tolerance, int maxiters,
+                  int zero_start, const double *true_x, double *x_out, double *objective, double *mses, int *n_iter,
+                  int flags);
+int csalsa_sharded(::sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                   const double *mu1, const double *mu2, const double *sigma, const double *epsilon,
+                   double continuationfactor, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
+                   double *x_out, double *objective, double *distance1, double *distance2, double *criterion,
+                   double *times, double *mses, int *numA, int *numAt, int *n_outer, int flags);
+int coral_sharded(::sbtv_group *g, const double *y, int M, int N, int n_items, const double *taps, int taille,
+                  const double *tau1, const double *tau2, const double *mu1, const double *mu2, const double *mu_ls,
+                  int TViters2, const sbtv_salsa_opts *opts, const double *true_x, const double *x_init, double *x_out,
+                  double *objective, double *distance, double *times, double *mses, int *numA, int *numAt, int *n_outer,
+                  int flags);
 
 // low-latency host waits of the solver loops (poll, then block; ctx.hip)
 int wait_event(sbtv_ctx *ctx, hipEvent_t ev);

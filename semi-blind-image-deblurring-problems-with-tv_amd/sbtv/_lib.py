@@ -79,6 +79,7 @@ SIGNATURES = {
     "sbtv_last_error": (C.c_char_p, [_P]),
     "sbtv_ctx_set_stream": (_I, [_P, _P]),
     "sbtv_ctx_sync": (_I, [_P]),
+    "sbtv_ctx_set_lanes": (_I, [_P, _I]),
     "sbtv_callcounter_get": (_I, [_P, C.POINTER(C.c_longlong)]),
     "sbtv_callcounter_reset": (_I, [_P]),
     "sbtv_last_timing": (_I, [_P, C.POINTER(_D)]),
@@ -116,6 +117,11 @@ SIGNATURES = {
                                    _P, _P, _P, _P, _P]),
     "sbtv_SAPG_algorithm_sharded": (_I, [_P, _P, _I, _I, _I, C.POINTER(sbtv_sapg_opts), _P, _P, _P, _P, _P, _P, _P, _P,
                                          _P, _P, _P]),
+    "sbtv_fista_tv_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _D, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
+    "sbtv_CSALSA_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _D, C.POINTER(sbtv_salsa_opts), _P, _P,
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sbtv_CoRAL_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, C.POINTER(sbtv_salsa_opts), _P,
+                                   _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
     "sbtv_last_host_stats": (_I, [_P, C.POINTER(_D)]),
@@ -187,6 +193,11 @@ class Context:
 
     def sync(self):
         self.check(self.lib.sbtv_ctx_sync(self.h))
+
+    def set_lanes(self, mode):
+        """0 (default): a batch of independent items is dealt to two internal streams; 1: one stream; 2: shared-gradient
+        chains are split as well (sbtv_ctx_set_lanes)."""
+        self.check(self.lib.sbtv_ctx_set_lanes(self.h, int(mode)))
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.sbtv_ctx_set_stream(self.h, _P(stream_ptr)))

@@ -92,12 +92,16 @@ def csalsa(y, A, mu1, mu2, sigma, *varargin, ctx=None, **kw):
     taps = A._cm(B)
     keep = [L.dvec(v, B) for v in (mu1, mu2, sigma, opts.get("EPSILON", 0.0))]     # (array, pointer) pairs stay alive
     m1, m2, sg, ep = (k[1] for k in keep)
-    ctx.check(ctx.lib.sbtv_CSALSA_v2(ctx.h, yi.ptr, M, N, B, _vp(taps), A.taille, m1, m2, sg, ep,
-                                     float(opts.get("CONTINUATIONFACTOR", 1.0)), C.byref(so),
-                                     ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr,
-                                     _vp(tr["objective"]), _vp(tr["distance1"]), _vp(tr["distance2"]),
-                                     _vp(tr["criterion"]), _vp(tr["times"]), _vp(tr["mses"]) if ti else None,
-                                     numA, numAt, nout, yi.flags), yi.flags)
+    args = (ctx.h, yi.ptr, M, N, B, _vp(taps), A.taille, m1, m2, sg, ep, float(opts.get("CONTINUATIONFACTOR", 1.0)),
+            C.byref(so), ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr, _vp(tr["objective"]),
+            _vp(tr["distance1"]), _vp(tr["distance2"]), _vp(tr["criterion"]), _vp(tr["times"]),
+            _vp(tr["mses"]) if ti else None, numA, numAt, nout)
+    if getattr(ctx, "is_group", False):          # sbtv.Group: images dealt to the devices in contiguous blocks
+        if yi.flags != L.SBTV_HOST_PTRS:
+            raise ValueError("a sbtv.Group takes host (NumPy) images")
+        ctx.check(ctx.lib.sbtv_CSALSA_v2_sharded(*args))
+    else:
+        ctx.check(ctx.lib.sbtv_CSALSA_v2(*args, yi.flags), yi.flags)
     sq = (y.dim() == 2) if yi.torch else yi.squeeze
     x = L.images_result(xo, sq)
     n = np.array(nout[:])
@@ -146,10 +150,15 @@ def CoRAL(y, A, tau1, tau2, *varargin, ctx=None, **kw):
     taps = A._cm(B)
     keep = [L.dvec(v, B) for v in (tau1, tau2, opts.get("MU1", 1e-3), opts.get("MU2", 1e-3), LS.mu)]
     t1, t2, m1, m2, ml = (k[1] for k in keep)
-    ctx.check(ctx.lib.sbtv_CoRAL_v2(ctx.h, yi.ptr, M, N, B, _vp(taps), A.taille, t1, t2, m1, m2, ml,
-                                    int(opts.get("TVITERS2", 5)), C.byref(so), ti.ptr if ti else None,
-                                    xinit.ptr if xinit else None, xo.ptr, _vp(objective), _vp(distance), _vp(times),
-                                    _vp(mses) if ti else None, numA, numAt, nout, yi.flags), yi.flags)
+    args = (ctx.h, yi.ptr, M, N, B, _vp(taps), A.taille, t1, t2, m1, m2, ml, int(opts.get("TVITERS2", 5)), C.byref(so),
+            ti.ptr if ti else None, xinit.ptr if xinit else None, xo.ptr, _vp(objective), _vp(distance), _vp(times),
+            _vp(mses) if ti else None, numA, numAt, nout)
+    if getattr(ctx, "is_group", False):          # sbtv.Group: images dealt to the devices in contiguous blocks
+        if yi.flags != L.SBTV_HOST_PTRS:
+            raise ValueError("a sbtv.Group takes host (NumPy) images")
+        ctx.check(ctx.lib.sbtv_CoRAL_v2_sharded(*args))
+    else:
+        ctx.check(ctx.lib.sbtv_CoRAL_v2(*args, yi.flags), yi.flags)
     sq = (y.dim() == 2) if yi.torch else yi.squeeze
     x = L.images_result(xo, sq)
     n = np.array(nout[:])

@@ -51,9 +51,18 @@ def my_fista(b, A, AT, tau, L_, Phi, Psi, stopcriterion, tolerance, maxiters, tr
     vp = L.vptr
     import time
     t0 = time.perf_counter()
-    ctx.check(ctx.lib.sbtv_fista_tv(ctx.h, bi.ptr, bi.M, bi.N, B, vp(taps), A.taille, tau_p, float(L_), Psi.maxiter,
-                                    int(stopcriterion), float(tolerance), K, 1 if _zero_start else 0, ti.ptr, xo.ptr,
-                                    vp(objective), vp(mses), nit, bi.flags | (L.FISTA_EXACT_PROX if exact_prox else 0)), bi.flags)
+    if getattr(ctx, "is_group", False):
+        # several GPUs behind this process (sbtv.Group): images dealt to the devices in contiguous blocks, no exchange
+        if bi.flags != L.SBTV_HOST_PTRS or exact_prox:
+            raise ValueError("a sbtv.Group takes host (NumPy) images (and no exact_prox flag)")
+        ctx.check(ctx.lib.sbtv_fista_tv_sharded(ctx.h, bi.ptr, bi.M, bi.N, B, vp(taps), A.taille, tau_p, float(L_),
+                                                Psi.maxiter, int(stopcriterion), float(tolerance), K,
+                                                1 if _zero_start else 0, ti.ptr, xo.ptr, vp(objective), vp(mses), nit))
+    else:
+        ctx.check(ctx.lib.sbtv_fista_tv(ctx.h, bi.ptr, bi.M, bi.N, B, vp(taps), A.taille, tau_p, float(L_), Psi.maxiter,
+                                        int(stopcriterion), float(tolerance), K, 1 if _zero_start else 0, ti.ptr, xo.ptr,
+                                        vp(objective), vp(mses), nit,
+                                        bi.flags | (L.FISTA_EXACT_PROX if exact_prox else 0)), bi.flags)
     wall = time.perf_counter() - t0
     sq = (b.dim() == 2) if bi.torch else bi.squeeze
     x = L.images_result(xo, sq)
