@@ -409,6 +409,9 @@ int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
  *   the context carries a 256-byte guard band on both sides and every entry point above ends by verifying all of
  *   them (SBTV_ERR_CANARY on damage).  This call verifies on demand: *enabled, number of guarded workspaces, damaged
  *   bytes.  poke = 1 first overwrites the rear guard of one workspace (self-test of the detector) and repairs it.
+ * sbtv_diag_stage_stats: cumulative staging of large pageable host arrays by this context (and its lanes): out = {bytes
+ *   host -> device, seconds, bytes device -> host, seconds}.  Arrays of >= 4 MB passed with SBTV_HOST_PTRS move through
+ *   four copy lanes (pinned chunks, own streams, SBTV_STAGE_THREADS = 0..4); smaller ones through a plain hipMemcpyAsync.
  * sbtv_diag_prox_variant: which TV-prox kernel a (M, N, batch) problem takes: out = {columns per wave, waves per
  *   workgroup, waves per SIMD requested, rows per lane, tiles per image, 2 = streaming pipeline kernel / 1 = temporally
  *   fused tile kernel / 0 = the one-iteration kernels (odd M, SBTV_SINGLE_STEP)} — lets a parity test assert which kernel it exercised.
@@ -432,6 +435,7 @@ int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
  *   only when the solve ran to MAXITERA).
  * sbtv_diag_switches: the SBTV_* environment switches that are set in this process, as "NAME=value ..." (returns their
  *   number; 0 and an empty string = the default kernels).  They are tuning / A-B hooks, read once per process. */
+int sbtv_diag_stage_stats(const sbtv_ctx *ctx, double out[4]);
 int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad);
 int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[14]);
 int sbtv_diag_workspace(sbtv_ctx *ctx, const char *name, void **dptr, size_t *bytes);

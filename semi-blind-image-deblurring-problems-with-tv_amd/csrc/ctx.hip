@@ -2,7 +2,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "sbtv_internal.h"
 
@@ -204,6 +207,108 @@ int twiddle_get(sbtv_ctx *ctx, int n, const double2 **out) {
     return 0;
 }
 
+// ---- staging of PAGEABLE host arrays (what a MATLAB or NumPy host hands over) -------------------------------------
+// A plain hipMemcpyAsync from / to pageable memory is staged by the runtime through one thread's memcpy: ~9 GB/s, 44 ms
+// for the 403 MB of four 2048^2 images in and out (BENCH_r03 `fixed_ms_per_call`) - six times the converged solve.  Large
+// arrays therefore go through kStageThreads copy lanes: thread t takes chunks t, t + T, ... of kStageChunk bytes, copies
+// each into one of its two pinned chunks while the DMA of the other is in flight (own stream, one event per chunk) - the
+// host-side memcpy, not PCIe, is the bound, so it is spread over several cores.  SBTV_STAGE_THREADS = 0 restores the plain copy.
+constexpr size_t kStageChunk = (size_t)4 << 20;
+constexpr int kStageMaxThreads = 4;
+static int stage_threads() {
+    static const int n = [] {
+        const char *e = getenv("SBTV_STAGE_THREADS");
+        const int v = e ? atoi(e) : kStageMaxThreads;
+        return v < 0 ? 0 : (v > kStageMaxThreads ? kStageMaxThreads : v);
+    }();
+    return n;
+}
+static int stage_init(sbtv_ctx *ctx) {
+    if (ctx->stage_ready) return 0;
+    for (auto &l : ctx->stage) {
+        SBTV_HIP(ctx, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            SBTV_HIP(ctx, hipHostMalloc(&l.pin[k], kStageChunk, hipHostMallocDefault));
+            SBTV_HIP(ctx, hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming));
+        }
+    }
+    ctx->stage_ready = true;
+    return 0;
+}
+// dst <- src for `bytes` bytes, to_device: src is pageable host memory and dst device memory, else the reverse.  Returns
+// when the data has arrived (the caller's stream is not involved: for a device source it must have been synchronised).
+static int stage_copy(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_device) {
+    // a lane stages its half of a batch while its twin stages the other half: two copy lanes each (eight memcpy threads
+    // on the two halves measured slower than four, tools/bench_hostcall.py)
+    const int T = ctx->is_lane ? std::min(2, stage_threads()) : stage_threads();
+    const auto t0 = std::chrono::steady_clock::now();
+    SBTV_TRY(stage_init(ctx));
+    const size_t nchunks = (bytes + kStageChunk - 1) / kStageChunk;
+    hipError_t errs[kStageMaxThreads];
+    for (auto &e : errs) e = hipSuccess;
+    auto lane = [&](int t) {
+        sbtv_ctx::StageLane &l = ctx->stage[t];
+        hipError_t e = hipSetDevice(ctx->device);
+        bool used[2] = {false, false};
+        auto span = [&](size_t c, size_t *off, size_t *len) {
+            *off = c * kStageChunk;
+            *len = std::min(kStageChunk, bytes - *off);
+        };
+        if (to_device) {
+            for (size_t c = (size_t)t, i = 0; c < nchunks && e == hipSuccess; c += (size_t)T, ++i) {
+                const int k = (int)(i & 1);
+                size_t off, len;
+                span(c, &off, &len);
+                if (used[k]) e = hipEventSynchronize(l.ev[k]);            // the DMA out of this pinned chunk has finished
+                if (e != hipSuccess) break;
+                memcpy(l.pin[k], (const char *)src + off, len);
+                e = hipMemcpyAsync((char *)dst + off, l.pin[k], len, hipMemcpyHostToDevice, l.s);
+                if (e == hipSuccess) e = hipEventRecord(l.ev[k], l.s);
+                used[k] = true;
+            }
+        } else {
+            // device -> pinned of chunk i+1 is in flight while chunk i moves pinned -> pageable
+            size_t off, len;
+            if ((size_t)t < nchunks) {
+                span((size_t)t, &off, &len);
+                e = hipMemcpyAsync(l.pin[0], (const char *)src + off, len, hipMemcpyDeviceToHost, l.s);
+                if (e == hipSuccess) e = hipEventRecord(l.ev[0], l.s);
+            }
+            for (size_t c = (size_t)t, i = 0; c < nchunks && e == hipSuccess; c += (size_t)T, ++i) {
+                const int k = (int)(i & 1);
+                const size_t cn = c + (size_t)T;
+                if (cn < nchunks) {
+                    size_t o2, l2;
+                    span(cn, &o2, &l2);
+                    e = hipMemcpyAsync(l.pin[k ^ 1], (const char *)src + o2, l2, hipMemcpyDeviceToHost, l.s);
+                    if (e == hipSuccess) e = hipEventRecord(l.ev[k ^ 1], l.s);
+                    if (e != hipSuccess) break;
+                }
+                e = hipEventSynchronize(l.ev[k]);
+                if (e != hipSuccess) break;
+                span(c, &off, &len);
+                memcpy((char *)dst + off, l.pin[k], len);
+            }
+        }
+        const hipError_t e2 = hipStreamSynchronize(l.s);
+        errs[t] = (e != hipSuccess) ? e : e2;
+    };
+    {
+        std::vector<std::thread> th;
+        const int nt = (int)std::min<size_t>((size_t)T, nchunks);
+        for (int t = 1; t < nt; ++t) th.emplace_back(lane, t);
+        lane(0);                                                       // the calling thread is lane 0
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < kStageMaxThreads; ++t)
+        if (errs[t] != hipSuccess) return fail_hip(ctx, errs[t], "stage_copy", __FILE__, __LINE__);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ctx->stage_stats[to_device ? 0 : 2] += (double)bytes;
+    ctx->stage_stats[to_device ? 1 : 3] += dt;
+    return 0;
+}
+static inline bool stage_threaded(size_t bytes) { return stage_threads() > 0 && bytes >= kStageChunk; }
+
 int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int flags, const double **dev) {
     if (p == nullptr) {
         *dev = nullptr;
@@ -215,7 +320,14 @@ int stage_in(sbtv_ctx *ctx, const char *name, const double *p, size_t count, int
     }
     double *d = nullptr;
     SBTV_TRY(ws_get_t(ctx, name, count, &d));
-    SBTV_HIP(ctx, hipMemcpyAsync(d, p, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (stage_threaded(count * sizeof(double))) {
+        // the workspace may still be read by work of an earlier call in the stream (entry points end synchronised, so
+        // this is a formality) - then the copy lanes write it
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SBTV_TRY(stage_copy(ctx, d, p, count * sizeof(double), true));
+    } else {
+        SBTV_HIP(ctx, hipMemcpyAsync(d, p, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     *dev = d;
     return 0;
 }
@@ -231,6 +343,10 @@ int stage_out_buf(sbtv_ctx *ctx, const char *name, double *p, size_t count, int 
 
 int stage_out_copy(sbtv_ctx *ctx, double *host, const double *dev, size_t count, int flags) {
     if (host == nullptr || (flags & SBTV_DEVICE_PTRS)) return 0;
+    if (stage_threaded(count * sizeof(double))) {
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the result is complete
+        return stage_copy(ctx, host, dev, count * sizeof(double), false);
+    }
     SBTV_HIP(ctx, hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return 0;
 }
@@ -382,6 +498,13 @@ int sbtv_ctx_destroy(sbtv_ctx *ctx) {
     for (auto &kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto &kv : ctx->any_axes) (void)hipFree(kv.second);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &l : ctx->stage) {
+        for (int k = 0; k < 2; ++k) {
+            if (l.pin[k]) (void)hipHostFree(l.pin[k]);
+            if (l.ev[k]) (void)hipEventDestroy(l.ev[k]);
+        }
+        if (l.s) (void)hipStreamDestroy(l.s);
+    }
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->loop_ev)
@@ -442,6 +565,15 @@ int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[14]) {
     return 0;
 }
 
+int sbtv_diag_stage_stats(const sbtv_ctx *ctx, double out[4]) {
+    if (!ctx || !out) return SBTV_ERR_BADARG;
+    for (int i = 0; i < 4; ++i) out[i] = ctx->stage_stats[i];
+    if (ctx->lanes)
+        for (int r = 0; r < sbtv_group_size(ctx->lanes); ++r)
+            for (int i = 0; i < 4; ++i) out[i] += sbtv_group_ctx(ctx->lanes, r)->stage_stats[i];
+    return 0;
+}
+
 int sbtv_diag_workspace(sbtv_ctx *ctx, const char *name, void **dptr, size_t *bytes) {
     if (!ctx || !name || !dptr) return SBTV_ERR_BADARG;
     auto it = ctx->ws.find(name);
@@ -458,7 +590,7 @@ int sbtv_diag_switches(char *buf, size_t cap) {
         "SBTV_CANARY", "SBTV_COLLECT_RIDE", "SBTV_EXACT", "SBTV_FFT_WAVE", "SBTV_FISTA_FUSED_STEP", "SBTV_FISTA_LAG",
         "SBTV_FUSED_VARIANT", "SBTV_GRAPH", "SBTV_INLINE_CTRL", "SBTV_PROX_SPEC", "SBTV_SAPG_DEFER",
         "SBTV_SAPG_FUSED_MYULA", "SBTV_SAPG_HOST", "SBTV_SINGLE_STEP", "SBTV_SPIN", "SBTV_TAG_SPIN_US", "SBTV_TILE_ORDER", "SBTV_ADMM_EXACT", "SBTV_SALSA_NOX", "SBTV_CSALSA_SPECTRAL",
-        "SBTV_CORAL_BATCH", "SBTV_ROWS_FOLD", "SBTV_ERR_SUBSET", "SBTV_LANES", "SBTV_LANE_COUNT"};
+        "SBTV_CORAL_BATCH", "SBTV_ROWS_FOLD", "SBTV_ERR_SUBSET", "SBTV_LANES", "SBTV_LANE_COUNT", "SBTV_STAGE_THREADS"};
     // variants that lost their measurements: only the lab build (make lab, -DSBTV_LAB) carries the kernels and reads these
     static const char *const lab_names[] = {"SBTV_PROX_PIPE", "SBTV_ROWS_KERNEL", "SBTV_ROWS_PIPE", "SBTV_ROWS_RK", "SBTV_ROWS_SUB", "SBTV_TAIL_HALF", "SBTV_TAIL_ROWS",
                                             "SBTV_ROWS_V", "SBTV_U_TILED"};
@@ -537,6 +669,11 @@ int sbtv_free(sbtv_ctx *ctx, void *dptr) {
 
 int sbtv_memcpy_h2d(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    if (stage_threaded(bytes)) {
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return stage_copy(ctx, dst, src, bytes, true);
+    }
     SBTV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -544,6 +681,11 @@ int sbtv_memcpy_h2d(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int sbtv_memcpy_d2h(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return SBTV_ERR_BADARG;
+    SBTV_HIP(ctx, hipSetDevice(ctx->device));
+    if (stage_threaded(bytes)) {
+        SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return stage_copy(ctx, dst, src, bytes, false);
+    }
     SBTV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

@@ -685,19 +685,20 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                                    (const double *)(gb[par] + (size_t)b * P), (const double *)(bub[par] + (size_t)b * P), dst, P);
                 SBTV_HIP(ctx, hipGetLastError());
             }
-            if (!dev_direct)
-                SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, dst, sizeof(double) * P,
-                                             (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                                             ctx->stream));
+            if (!dev_direct && (flags & SBTV_DEVICE_PTRS))
+                SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, dst, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+            else if (!dev_direct)
+                SBTV_TRY(stage_out_copy(ctx, x_out + (size_t)b * P, dst, P, flags));        // host: through the copy lanes
         }
     } else if (x_out) {
         // image b's result is the x written by ITS last processed iteration
         for (int b = 0; b < batch; ++b) {
             if (direct_last && h_nouter[b] == maxiter) continue;        // already there
             const double *src = xbuf[h_nouter[b] & 1] + (size_t)b * P;
-            SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, src, sizeof(double) * P,
-                                         (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                                         ctx->stream));
+            if (flags & SBTV_DEVICE_PTRS)
+                SBTV_HIP(ctx, hipMemcpyAsync(x_out + (size_t)b * P, src, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+            else
+                SBTV_TRY(stage_out_copy(ctx, x_out + (size_t)b * P, src, P, flags));        // host: through the copy lanes
         }
     }
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the one synchronisation of the call

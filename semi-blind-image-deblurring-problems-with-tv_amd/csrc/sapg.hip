@@ -1369,8 +1369,10 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         SBTV_HIP(ctx, hipMemcpyAsync(tr.data(), tr_d, sizeof(double) * ntr, hipMemcpyDeviceToHost, ctx->stream));
         SBTV_HIP(ctx, hipMemcpyAsync(ch.data(), chain_d, sizeof(SapgChain) * batch, hipMemcpyDeviceToHost, ctx->stream));
         if (x_last) {
-            SBTV_HIP(ctx, hipMemcpyAsync(x_last, X, sizeof(double) * cnt,
-                                         (flags & SBTV_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+            if (flags & SBTV_DEVICE_PTRS)
+                SBTV_HIP(ctx, hipMemcpyAsync(x_last, X, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+            else
+                SBTV_TRY(stage_out_copy(ctx, x_last, X, cnt, flags));
         }
         SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const double *h_theta = tr.data(), *h_sigma = h_theta + bs, *h_logpi = h_theta + 2 * bs, *h_gx = h_theta + 3 * bs,
@@ -1545,7 +1547,7 @@ int sbtv_SAPG_algorithm(sbtv_ctx *ctx, const double *y, int M, int N, int batch,
         if (flags & SBTV_DEVICE_PTRS)
             SBTV_HIP(ctx, hipMemcpyAsync(x_last, X, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
         else
-            SBTV_HIP(ctx, hipMemcpyAsync(x_last, X, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+            SBTV_TRY(stage_out_copy(ctx, x_last, X, cnt, flags));
     }
     SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)nsteps_noise;

@@ -137,6 +137,15 @@ struct sbtv_ctx {
     int cu_count = 256;
     // SBTV_CANARY=1 (read when the context is created): every workspace gets a guard band on both sides,
     // verified at the end of each C-ABI call (canary_epilogue)
+    // Host <-> device staging of large pageable arrays (ctx.hip `stage_copy`): kStageThreads copy lanes, each with its
+    // own stream, two pinned chunks and an event per chunk (created on first use)
+    struct StageLane {
+        hipStream_t s = nullptr;
+        void *pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    } stage[4];
+    bool stage_ready = false;
+    double stage_stats[4] = {0, 0, 0, 0};     // cumulative: bytes in, seconds in, bytes out, seconds out (sbtv_diag_stage_stats)
     // Lanes: a batch of independent items (images, chains) is dealt to two internal contexts on this device, one host
     // thread and one stream each, so that the launch tails and the memory-bound passes of one half run under the
     // issue-bound Chambolle launches of the other (csrc/group.hip, `lanes_group`).  Image k is computed bit for bit as

@@ -122,6 +122,7 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sbtv_CoRAL_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, C.POINTER(sbtv_salsa_opts), _P,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sbtv_diag_stage_stats": (_I, [_P, C.POINTER(_D)]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
     "sbtv_last_host_stats": (_I, [_P, C.POINTER(_D)]),
@@ -198,6 +199,12 @@ class Context:
         """0 (default): a batch of independent items is dealt to two internal streams; 1: one stream; 2: shared-gradient
         chains are split as well (sbtv_ctx_set_lanes)."""
         self.check(self.lib.sbtv_ctx_set_lanes(self.h, int(mode)))
+
+    def stage_stats(self):
+        """Cumulative staging of large host arrays by this context and its lanes (sbtv_diag_stage_stats)."""
+        out = (C.c_double * 4)()
+        self.check(self.lib.sbtv_diag_stage_stats(self.h, out))
+        return dict(bytes_in=out[0], s_in=out[1], bytes_out=out[2], s_out=out[3])
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.sbtv_ctx_set_stream(self.h, _P(stream_ptr)))
@@ -393,10 +400,12 @@ def images_result(img: Images, squeeze=None):
     """Back to the caller's convention: numpy (M,N)/(B,M,N) or the torch tensor."""
     if img.torch:
         return img.t[0] if squeeze else img.t
+    # a VIEW of the column-major buffer the library wrote (shape (B, M, N), Fortran-ordered images): a row-major copy of
+    # four 2048^2 images costs more than their whole solve (tools/bench_hostcall.py)
     a = np.transpose(img.buf, (0, 2, 1))
     if squeeze is None:
         squeeze = getattr(img, "squeeze", False)
-    return np.array(a[0] if squeeze else a)
+    return a[0] if squeeze else a
 
 
 def to_device(x, device="cuda:0"):
