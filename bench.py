@@ -246,11 +246,16 @@ def chambolle_roofline(tm, size, pmc, pmc_state, kind="tile", split=None):
         roof["valu_wave_insts_per_launch"] = k["valu_insts_per_launch"]
         # instructions spent on core pixels only (the halo of the temporal blocking is recomputed work)
         roof["useful_frac"] = roof["valu_issue_frac"] * k.get("core_fraction", 1.0)
-    tl = load_timeline()
-    if tl:
-        roof["tail_frac"] = tl["tail_us"] / tl["launch_us"]
-        roof["tail"] = {"launch_us": tl["launch_us"], "tail_us": tl["tail_us"], "file": "profiles/timeline_current.json",
-                        "measured_on_current_sources": tl["current_sources"]}
+    try:
+        tl = load_timeline()
+        if tl and tl.get("launch_us") and tl.get("tail_us") is not None:
+            current = bool(tl.get("current_sources"))
+            # a timeline measured on other sources says nothing about this build's tail: the fraction is then withheld
+            roof["tail_frac"] = (tl["tail_us"] / tl["launch_us"]) if current else None
+            roof["tail"] = {"launch_us": tl["launch_us"], "tail_us": tl["tail_us"], "file": "profiles/timeline_current.json",
+                            "measured_on_current_sources": current}
+    except Exception as e:               # an older or damaged file must not take the headline line down
+        roof["tail"] = {"error": str(e)}
     if split and "per_iteration_us" in split:
         roof["split"] = dict(split)
         if k and k.get("valu_insts_per_launch"):

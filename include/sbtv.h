@@ -409,6 +409,9 @@ int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
  *   the context carries a 256-byte guard band on both sides and every entry point above ends by verifying all of
  *   them (SBTV_ERR_CANARY on damage).  This call verifies on demand: *enabled, number of guarded workspaces, damaged
  *   bytes.  poke = 1 first overwrites the rear guard of one workspace (self-test of the detector) and repairs it.
+ * sbtv_diag_solve_stats: cumulative, this context and its lanes: out = {solves repeated with exact Chambolle launches because
+ *   the stop rule (chambolle_prox_TV_stop.m:131) fired inside an optimistic prox, switches of a solve from subset error sums
+ *   back to full sums, 0, 0}.
  * sbtv_diag_stage_stats: cumulative staging of large pageable host arrays by this context (and its lanes): out = {bytes
  *   host -> device, seconds, bytes device -> host, seconds}.  Arrays of >= 4 MB passed with SBTV_HOST_PTRS move through
  *   four copy lanes (pinned chunks, own streams, SBTV_STAGE_THREADS = 0..4); smaller ones through a plain hipMemcpyAsync.
@@ -435,6 +438,7 @@ int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
  *   only when the solve ran to MAXITERA).
  * sbtv_diag_switches: the SBTV_* environment switches that are set in this process, as "NAME=value ..." (returns their
  *   number; 0 and an empty string = the default kernels).  They are tuning / A-B hooks, read once per process. */
+int sbtv_diag_solve_stats(const sbtv_ctx *ctx, double out[4]);
 int sbtv_diag_stage_stats(const sbtv_ctx *ctx, double out[4]);
 int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad);
 int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[14]);

@@ -381,7 +381,7 @@ inline int admm_prox(sbtv_ctx *ctx, const ProxPlan &pp, const double *g, int K, 
 // cont = (k < MaxIter) & (err > tol) over the K step sums: did the rule stop before the last step?
 inline bool admm_fired_early(const double *stepsums, int K, double tol) {
     for (int k = 1; k < K; ++k)
-        if (!(sqrt(stepsums[k - 1]) > tol)) return true;
+        if (!(sqrt(stepsums[k - 1]) > tol * SPEC_TOL_GUARD)) return true;
     return false;
 }
 // the step sums of launches that sum a subset of the pixels are lower bounds (ProxPlan::esub_off): are they still far from tol^2?
@@ -638,7 +638,10 @@ int csalsa_one(sbtv_ctx *ctx, const double *yd, int M, int N, const double *taps
             fired = true;
             return 0;
         }
-        if (spec && !pp.esub_off && admm_sums_near_tol(hsl + 16, K, opts->chambolle_tol)) pp.esub_off = 1;
+        if (spec && !pp.esub_off && admm_sums_near_tol(hsl + 16, K, opts->chambolle_tol)) {
+            pp.esub_off = 1;
+            ctx->solve_stats[1] += 1;
+        }
         prox_iters += spec ? K : *reinterpret_cast<const int *>(hsl + 8);
         h_numAt += 1;
         h_numA += 1;
@@ -978,6 +981,7 @@ int sbtv_CSALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, cons
                                       n_outer ? n_outer + b : nullptr, attempt == 0);
             if (rc == ADMM_RESTART_EXACT && attempt == 0) {
                 ctx->calls = calls0;
+                ctx->solve_stats[0] += 1;
                 continue;
             }
             SBTV_TRY(rc);
@@ -1029,6 +1033,7 @@ int sbtv_CoRAL_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                                      numAt ? numAt + b : nullptr, n_outer ? n_outer + b : nullptr, attempt == 0);
             if (rc == ADMM_RESTART_EXACT && attempt == 0) {
                 ctx->calls = calls0;
+                ctx->solve_stats[0] += 1;
                 continue;
             }
             SBTV_TRY(rc);

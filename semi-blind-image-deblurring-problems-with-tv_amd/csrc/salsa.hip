@@ -589,7 +589,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                 const double *ps = psum_h + ((size_t)slot * batch + b) * FSTRIDE;
                 prox_k = (double)opts->TViters;
                 for (int k = 1; k < opts->TViters; ++k)
-                    if (!(sqrt(ps[k - 1]) > opts->chambolle_tol)) {
+                    if (!(sqrt(ps[k - 1]) > opts->chambolle_tol * SPEC_TOL_GUARD)) {
                         fired_early = true;          // the rule stopped before the last step: start over, exactly
                         break;
                     }
@@ -597,7 +597,10 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
                 // the sums of launches that sum a subset of the pixels are lower bounds: long before they can come near
                 // tol^2 the launches of this solve go back to the full sums (ProxPlan::esub_off)
                 for (int k = 1; k <= opts->TViters && !pp.esub_off; ++k)
-                    if (!(ps[k - 1] > ESUB_MARGIN * opts->chambolle_tol * opts->chambolle_tol)) pp.esub_off = 1;
+                    if (!(ps[k - 1] > ESUB_MARGIN * opts->chambolle_tol * opts->chambolle_tol)) {
+                        pp.esub_off = 1;
+                        ctx->solve_stats[1] += 1;
+                    }
             }
             prox_iters_run += (long long)prox_k;
             ctx->calls += 2;   // invLS + A (callcounter)
@@ -656,6 +659,7 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
     if (fired_early) {
         SBTV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->calls = calls_at_entry;
+        ctx->solve_stats[0] += 1;
         sbtv_salsa_opts exact = *opts;
         exact.speculate = (opts->speculate & 1) | 2;
         return sbtv_SALSA_v2(ctx, y, M, N, batch, taps, taille, tau, mu, &exact, true_x, x_init, x_out, objective, distance,

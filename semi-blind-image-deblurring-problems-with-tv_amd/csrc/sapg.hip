@@ -674,10 +674,13 @@ int sbtv_fista_tv(sbtv_ctx *ctx, const double *bimg, int M, int N, int batch, co
             for (int b = 0; b < batch && !fired; ++b) {
                 if (frozen[b]) continue;
                 const double *ps = sc + 8 * (size_t)batch + (size_t)b * FSTRIDE;
-                for (int kk = 1; kk < prox_iters && !fired; ++kk) fired = !(sqrt(ps[kk - 1]) > 1e-3);
+                for (int kk = 1; kk < prox_iters && !fired; ++kk) fired = !(sqrt(ps[kk - 1]) > 1e-3 * SPEC_TOL_GUARD);
                 // (lower-bound sums of the subset launches: back to the full sums long before they can reach tol^2)
                 for (int kk = 1; kk <= prox_iters && !pp.esub_off; ++kk)
-                    if (!(ps[kk - 1] > ESUB_MARGIN * 1e-6)) pp.esub_off = 1;
+                    if (!(ps[kk - 1] > ESUB_MARGIN * 1e-6)) {
+                        pp.esub_off = 1;
+                        ctx->solve_stats[1] += 1;
+                    }
             }
             if (fired) return 0;
         }

@@ -146,6 +146,9 @@ struct sbtv_ctx {
     } stage[4];
     bool stage_ready = false;
     double stage_stats[4] = {0, 0, 0, 0};     // cumulative: bytes in, seconds in, bytes out, seconds out (sbtv_diag_stage_stats)
+    // cumulative (sbtv_diag_solve_stats): solves repeated with exact Chambolle launches because the stop rule fired inside
+    // an optimistic prox; switches of a solve from subset error sums back to full sums (ProxPlan::esub_off)
+    double solve_stats[4] = {0, 0, 0, 0};
     // Lanes: a batch of independent items (images, chains) is dealt to two internal contexts on this device, one host
     // thread and one stream each, so that the launch tails and the memory-bound passes of one half run under the
     // issue-bound Chambolle launches of the other (csrc/group.hip, `lanes_group`).  Image k is computed bit for bit as
@@ -350,6 +353,10 @@ int prox_get_duals(sbtv_ctx *ctx, const ProxPlan &pl, double *px, double *py);  
 // cold = true: start from px = py = 0 without reading (or requiring the caller to clear) the dual buffer; the
 // control block must have been reset with keep_cur = false.
 constexpr int FSMAX = 10;     // most iterations any fused Chambolle kernel runs per LAUNCH
+// The after-the-fact check of an optimistic prox compares step sums that were added up in another order than the exact
+// launches' (and, with ESUB, over a subset of the pixels) with tol: a sum within this relative band above tol counts as
+// "fired" too and takes the exact path, so that the certificate "the rule did not fire" holds in floating point as well
+constexpr double SPEC_TOL_GUARD = 1.0 + 1e-12;
 constexpr double ESUB_MARGIN = 32.0;    // see ProxPlan::esub_off (step sums move by a few per cent per outer iteration, the host is one behind)
 constexpr int FSTRIDE = 32;   // step slots of the error partials [batch][FSTRIDE][nblk]: most iterations of an optimistic prox
 // ---- SALSA collector: what it reduces (salsa.hip launches it; the Chambolle kernels can host its blocks, tv_fused.inc)
@@ -500,6 +507,7 @@ struct RedJobs {
     double *dst[4] = {nullptr, nullptr, nullptr, nullptr};
     int nvec[4] = {0, 0, 0, 0};
     int n[4] = {0, 0, 0, 0};
+    int dropped = 0;               // jobs that found all four slots taken: reduce_jobs refuses such a set
     void add(const double *s, int nv, int nn, double *d) {
         for (int q = 0; q < 4; ++q)
             if (nvec[q] == 0) {
@@ -509,6 +517,7 @@ struct RedJobs {
                 n[q] = nn;
                 return;
             }
+        ++dropped;
     }
 };
 int reduce_jobs(sbtv_ctx *ctx, const RedJobs &jb);

@@ -1152,6 +1152,7 @@ int prox_finish(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, double *f) {
 }
 
 int reduce_jobs(sbtv_ctx *ctx, const RedJobs &jb) {
+    if (jb.dropped) return fail(ctx, SBTV_ERR_BADARG, "reduce_jobs: more than four jobs in one launch (a reduction would be skipped)");
     int tot = 0;
     for (int q = 0; q < 4; ++q) tot += jb.nvec[q];
     if (tot <= 0) return 0;

@@ -123,6 +123,7 @@ SIGNATURES = {
     "sbtv_CoRAL_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, C.POINTER(sbtv_salsa_opts), _P,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sbtv_diag_stage_stats": (_I, [_P, C.POINTER(_D)]),
+    "sbtv_diag_solve_stats": (_I, [_P, C.POINTER(_D)]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
     "sbtv_last_host_stats": (_I, [_P, C.POINTER(_D)]),
@@ -199,6 +200,13 @@ class Context:
         """0 (default): a batch of independent items is dealt to two internal streams; 1: one stream; 2: shared-gradient
         chains are split as well (sbtv_ctx_set_lanes)."""
         self.check(self.lib.sbtv_ctx_set_lanes(self.h, int(mode)))
+
+    def solve_stats(self):
+        """Cumulative: exact_restarts (solves repeated with exact Chambolle launches), esub_off (switches from subset error
+        sums back to full sums) of this context and its lanes (sbtv_diag_solve_stats)."""
+        out = (C.c_double * 4)()
+        self.check(self.lib.sbtv_diag_solve_stats(self.h, out))
+        return dict(exact_restarts=int(out[0]), esub_off=int(out[1]))
 
     def stage_stats(self):
         """Cumulative staging of large host arrays by this context and its lanes (sbtv_diag_stage_stats)."""

@@ -383,15 +383,19 @@ def test_long_solve_keeps_its_optimistic_launches(ctx, man512):
     yd, xd = sbtv.to_device(st["y"]), sbtv.to_device(man512)
     mu, tau = 0.003, 0.03 * st["sigma"] ** 2
 
-    def per_iteration_ms(K):
-        best = 1e9
-        for _ in range(2):
-            sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0, "MAXITERA", K,
-                          "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
-            best = min(best, ctx.last_timing()["loop_ms"] / K)
-        return best
-    short, long_ = per_iteration_ms(300), per_iteration_ms(2500)
-    assert long_ < 1.35 * short, (short, long_)
+    def solve(K):
+        s0 = ctx.solve_stats()
+        sbtv.SALSA_v2(yd, A, tau, "MU", mu, "AT", A.T, "LS", A.LS(mu), "True_x", xd, "ToleranceA", -1.0, "MAXITERA", K,
+                      "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+        s1 = ctx.solve_stats()
+        return {k: s1[k] - s0[k] for k in s0}, ctx.last_timing()["loop_ms"] / K
+    short, t_short = solve(300)
+    long_, t_long = solve(2500)
+    # the mechanism itself (the timing ratio this test used to assert moved with the box's clocks): neither solve took the
+    # exact path, and the long one switched to full sums exactly once
+    assert short == dict(exact_restarts=0, esub_off=0), short
+    assert long_ == dict(exact_restarts=0, esub_off=1), long_
+    print(f"per iteration: {t_short:.4f} ms (300 iterations), {t_long:.4f} ms (2500)")
 
 
 def test_tap_spectrum_kept_across_calls_only_for_the_same_taps(cman256):
