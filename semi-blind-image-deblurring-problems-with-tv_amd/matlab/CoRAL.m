@@ -6,11 +6,19 @@ persistent ctx
 if isempty(ctx), ctx = sbtv_load(0); end
 stopCriterion = 1; maxiter = 10000; init = 0; AT = 0; tolA = 0.001; mu1 = 1e-3; mu2 = 1e-3; isTV1 = 0; isTV2 = 0;
 TViters1 = 5; TViters2 = 5; verbose = 1; isinvLS = 0; invLS = []; compute_mse = 0; true_x = []; xinit = []; h = [];
+dP = [0 0 0 0]; Pops = {[], [], [], []};      % P1, P1T, P2, P2T (CoRAL_v2.m:61-72)
 if (rem(length(varargin),2)==1), error('Optional parameters should always go by pairs'); end
 for i = 1:2:(length(varargin)-1)
     switch upper(varargin{i})
         case 'PSF',               h = varargin{i+1};
-        case {'PSI1','PHI1','PSI2','PHI2'}    % accepted and ignored on the TV paths
+        case {'PSI1','PHI1','PSI2','PHI2'}    % accepted and ignored on the TV paths (CoRAL_v2.m:79-92,229-231,277-279)
+        % options the reference parses but whose only uses are in commented-out code (CoRAL_v2.m:479-563): no effect
+        % there, none here
+        case {'W','WT','MASK','UNITARYTRANSFORMDOMAINMASK','CONVOLUTIONFILTER','INNERITERS'}    % CoRAL_v2.m:55-60,73-78,103-104
+        case 'P1',                dP(1) = 1; Pops{1} = varargin{i+1};
+        case 'P1T',               dP(2) = 1; Pops{2} = varargin{i+1};
+        case 'P2',                dP(3) = 1; Pops{3} = varargin{i+1};
+        case 'P2T',               dP(4) = 1; Pops{4} = varargin{i+1};
         case 'TVINITIALIZATION1', isTV1 = varargin{i+1};
         case 'TVINITIALIZATION2', isTV2 = varargin{i+1};
         case 'TVITERS1',          TViters1 = varargin{i+1};
@@ -34,6 +42,9 @@ if isa(A, 'function_handle') && ~isa(AT,'function_handle'), error('The function 
 if ~isinvLS, error('(A^T A + \mu I)^(-1) must be specified as a function handle.\n'); end
 if ~(isTV1 && isTV2), error('sbtv:CoRAL', 'only the TV + TV problem runs on the GPU path'); end
 [M, N] = size(y);
+% r = ATy + mu1*P1(u+bu) + mu2*P2(v+bv), P1Tx = P1T(x), P2Tx = P2T(x) (CoRAL_v2.m:349-350,411,417-418): identity only
+sbtv_check_identity('sbtv:CoRAL', Pops{1}, Pops{2}, dP(1), dP(2), M, N, 'P1', 'P1T');
+sbtv_check_identity('sbtv:CoRAL', Pops{3}, Pops{4}, dP(3), dP(4), M, N, 'P2', 'P2T');
 if isempty(h), h = sbtv_psf_of_handle(A, M, N); end
 mu_ls = mu1 + mu2;                          % CoRAL_v2.m:137; a different filter weight is read off the 'LS' handle
 if isa(invLS, 'function_handle')

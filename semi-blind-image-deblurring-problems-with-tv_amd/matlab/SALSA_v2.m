@@ -13,13 +13,17 @@ persistent ctx
 if isempty(ctx), ctx = sbtv_load(0); end
 stopCriterion = 1; maxiter = 10000; init = 0; AT = 0; mu = 1e-3; tolA = 0.001;
 isTVinitialization = 0; TViters = 5; verbose = 1; isinvLS = 0; invLS = []; compute_mse = 0; h = []; true_x = []; xinit = [];
+definedP = 0; definedPT = 0; P = []; PT = [];
 if (rem(length(varargin),2)==1)
     error('Optional parameters should always go by pairs');
 end
 for i = 1:2:(length(varargin)-1)
     switch upper(varargin{i})
         case 'PSF',              h = varargin{i+1};
-        case {'PSI','PHI','P','PT'}   % accepted and ignored on the TV path (SALSA_v2.m:318-320)
+        case {'PSI','PHI'}       % accepted and ignored: with 'TVINITIALIZATION' = 1 the reference ignores them too
+                                 % and prints a warning (SALSA_v2.m:318-320,354-359, quirk Q7)
+        case 'P',                definedP = 1; P = varargin{i+1};      % SALSA_v2.m:198-200
+        case 'PT',               definedPT = 1; PT = varargin{i+1};    % SALSA_v2.m:201-203
         case 'TVINITIALIZATION', isTVinitialization = varargin{i+1};
         case 'TVITERS',          TViters = varargin{i+1};
         case 'MU',               mu = varargin{i+1};
@@ -43,6 +47,7 @@ end
 if ~isinvLS, error('(A^T A + \mu I)^(-1) must be specified as a function handle.\n'); end
 if ~isTVinitialization, error('sbtv:SALSA_v2', 'only ''TVINITIALIZATION'',1 runs on the GPU path'); end
 [M, N] = size(y);
+sbtv_check_identity('sbtv:SALSA_v2', P, PT, definedP, definedPT, M, N, 'P', 'PT');   % r = ATy + mu*P(u+bu) (SALSA_v2.m:434)
 delta = zeros(M, N); delta(1,1) = 1;
 if isempty(h)
     if ~isa(A, 'function_handle'), error('sbtv:SALSA_v2', 'A must be a function handle (or pass ''PSF'', h)'); end

@@ -5,12 +5,14 @@ function [x, numA, numAt, objective, distance1, distance2, criterion, times, mse
 persistent ctx
 if isempty(ctx), ctx = sbtv_load(0); end
 stopCriterion = 3; maxiter = 10000; init = 0; AT = 0; tolA = 0.001; isTV = 0; TViters = 5; verbose = 1; isinvLS = 0;
-delta = 1; epsilon = 0; compute_mse = 0; true_x = []; xinit = []; h = [];
+delta = 1; epsilon = 0; compute_mse = 0; true_x = []; xinit = []; h = []; definedP = 0; definedPT = 0; P = []; PT = [];
 if (rem(length(varargin),2)==1), error('Optional parameters should always go by pairs'); end
 for i = 1:2:(length(varargin)-1)
     switch upper(varargin{i})
         case 'PSF',                h = varargin{i+1};
-        case {'PSI','PHI','P','PT'}     % accepted and ignored on the TV path
+        case {'PSI','PHI'}         % accepted and ignored on the TV path (CSALSA_v2.m:331-333: ignored with a warning)
+        case 'P',                  definedP = 1; P = varargin{i+1};       % CSALSA_v2.m:208-210
+        case 'PT',                 definedPT = 1; PT = varargin{i+1};     % CSALSA_v2.m:211-213
         case 'TVINITIALIZATION',   isTV = varargin{i+1};
         case 'TVITERS',            TViters = varargin{i+1};
         case 'STOPCRITERION',      stopCriterion = varargin{i+1};
@@ -32,6 +34,7 @@ if isa(A, 'function_handle') && ~isa(AT,'function_handle'), error('The function 
 if ~isinvLS, error('(A^T A + \mu I)^(-1) must be specified as a function handle.\n'); end
 if ~isTV, error('sbtv:csalsa', 'only ''TVINITIALIZATION'',1 runs on the GPU path'); end
 [M, N] = size(y);
+sbtv_check_identity('sbtv:csalsa', P, PT, definedP, definedPT, M, N, 'P', 'PT');     % PTx = PT(x) (CSALSA_v2.m:402,473)
 if isempty(h), h = sbtv_psf_of_handle(A, M, N); end
 o = libstruct('sbtv_salsa_opts');
 calllib('libsbtv', 'sbtv_salsa_opts_default', o);
