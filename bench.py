@@ -342,6 +342,53 @@ def median(v):
     return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
 
 
+CONFIGS_FILE = os.path.join(ROOT, "profiles", "configs_current.json")
+# Byte models of the fused design per unit and pixel (fp64; a half spectrum S or an operator spectrum = 8 B per pixel):
+#   cold prox(25) = 5 Chambolle launches: 24 (read g, write px, py) + 3 x 40 + 48 (last one also writes f)      = 192
+#   forward column pass 16 (+ TV partials), row pass with S in and out + two operator spectra 32, inverse column pass fused
+#   with its consumer (gradient step / MYULA step) 24 / 32
+CONFIG_MODELS = {
+    # my_fista iteration (SALSA/my_fista.m:22-33): cols(y) 16 + rows GRADF 32 + cols^-1 with the gradient step 24 + prox 192
+    # + momentum (x, x_old, true in, y out) 32 + objective: cols(x) 16 + residual rows (S, H, Y in) 24
+    "3": dict(bytes_per_px=336.0, px=2048 * 2048, unit="FISTA iteration"),
+    # SAPG Laplace image-iteration, PSF moving: tap + derivative spectra written 16, rows GRADF 32, cols^-1 + MYULA step 32,
+    # prox 192, cols(X) 16, gradient-sums rows (S, H, Y, D in) 32
+    "4": dict(bytes_per_px=320.0, px=1024 * 1024, unit="image-iteration"),
+    # SAPG Gaussian chain-iteration, PSF fixed, 4 chains share the operator spectra (read once per row block for all
+    # chains: 32 / 4): cols^-1 + MYULA 32, prox 192, cols(X) 16, rows GRAD with inverse 16 + 8
+    "5": dict(bytes_per_px=264.0, px=2048 * 2048, unit="chain-iteration"),
+    # the demo's loop at 512^2 (fixed PSF, one chain): same passes, spectra not shared
+    "6": dict(bytes_per_px=288.0, px=512 * 512, unit="iteration"),
+}
+
+
+def config_roofline(cfg, units_per_s):
+    """`roofline` of an extra_configs entry: algorithmic bytes of the fused design per unit x measured units/s against the
+    HBM peak, and - from profiles/configs_current.json (tools/profile_config.sh, stamped with the hash of the kernel
+    sources) - the PMC bytes of one iteration, the dominant kernel and the launches per iteration of the profiled run."""
+    m = CONFIG_MODELS[cfg]
+    model = m["bytes_per_px"] * m["px"]
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "model_bytes_per_" + m["unit"].replace("-", "_").replace(" ", "_"): model,
+         "achieved": model * units_per_s / 1e9, "frac": model * units_per_s / 1e9 / HBM_PEAK_GBS, "traffic": None}
+    try:
+        d = json.load(open(CONFIGS_FILE))
+        if d.get("source_sha256") != source_sha():
+            r["pmc_file"] = "stale (measured on other kernel sources)"
+            return r
+        c = d["configs"][cfg]
+        r["pmc_file"] = "ok"
+        r["traffic"] = c["hbm_bytes_per_iteration"]
+        r["traffic_is"] = "PMC bytes of ONE iteration of all local units in the profiled run (%s)" % c["tag"]
+        r["profiled_us_per_iteration"] = c["us_per_iteration"]
+        r["traffic_frac"] = c["hbm_bytes_per_iteration"] / (c["us_per_iteration"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        r["dominant_kernel"] = c["dominant_kernel"]
+        r["dominant_kernel_share_of_gpu_time"] = c["dominant_kernel_share"]
+        r["launches_per_iteration"] = c["launches_per_iteration"]
+    except Exception as e:
+        r["pmc_file"] = "missing (%s)" % type(e).__name__
+    return r
+
+
 def extra_configs(ctx, dev, iters):
     """One GPU's share of BASELINE configs[2..4], `iters` iterations each after a short pre-roll, timed by this process
     (host clock around the C-ABI call, inputs device-resident).  The code of tools/bench_sapg.py, which also runs them
@@ -365,17 +412,18 @@ def extra_configs(ctx, dev, iters):
     dt = time.perf_counter() - t0
     out["fista_2048_moffat"] = {"workload": "my_fista + cold Chambolle(25), 2048x2048, Moffat PSF (configs[2])",
                                 "value": iters / dt, "unit": "FISTA iterations/s", "steps": iters,
-                                "ms_per_iteration": 1e3 * dt / iters}
+                                "ms_per_iteration": 1e3 * dt / iters, "roofline": config_roofline("3", iters / dt)}
     del yd, xd
 
-    def sapg(kind, size, nunits, share):
-        xx = tiled_image(size)
+    def sapg(kind, size, nunits, share, its=None, img=None):
+        iters_ = iters if its is None else its
+        xx = tiled_image(size) if img is None else img
         s2 = sbtv.demo_setup(kind, xx, rng.standard_normal(xx.shape), evMax=0.99, ctx=ctx)
         d = {"gaussian": dict(names=("w1", "w2"), init=(0.5, 0.3), pmin=(0.1, 0.1), pmax=(1.0, 1.0), fix=(1, 1),
                               c=dict(theta=0.01, w1=10.0, w2=10.0, sigma=1000.0)),
              "laplace": dict(names=("b",), init=(0.1,), pmin=(1e-3,), pmax=(1.0,), fix=(0,),
                              c=dict(theta=0.01, b=100.0, sigma=1e4))}[kind]
-        op = dict(samples=iters + 1, warmup=0, burnIn=2, psf_size=7, phi=0.0, gamma=s2["gamma"], th_init=0.01,
+        op = dict(samples=iters_ + 1, warmup=0, burnIn=2, psf_size=7, phi=0.0, gamma=s2["gamma"], th_init=0.01,
                   min_th=1e-3, max_th=1.0, sigma=s2["sigma"], sigma_init=s2["sigma_init"], sigma_min=s2["sigma_min"],
                   sigma_max=s2["sigma_max"], d_scale=1.0, d_exp=0.8, fix_sigma=0)
         op["lambda"] = s2["lambda"]
@@ -423,29 +471,58 @@ def extra_configs(ctx, dev, iters):
         t2 = time.perf_counter()
         run(n_b)
         t3 = time.perf_counter()
+        # the fixed part of a call measured directly: calls of 2 iterations (the intercept of two call lengths also holds
+        # whatever is not linear in the iteration count - the first iterations of a call run exact launches and on lower
+        # clocks - and came out at twice this, tools/bench_hostcall.py)
+        short_calls = []
+        for _ in range(3):
+            ts = time.perf_counter()
+            run(2)
+            short_calls.append(time.perf_counter() - ts)
         g.close()
         slope = ((t3 - t2) - (t2 - t1)) / (n_b - n_a)
         out["group_2_virtual_shards_4x2048"] = {
             "workload": "sbtv_SALSA_v2_sharded: 4 images of the headline problem over a group of two contexts on THIS GPU "
                         "(virtual shards: two host threads, no second device to gain from), host buffers in and out",
             "value": 4.0 / slope, "unit": "image-iterations/s", "value_is": "slope between calls of %d and %d outer iterations" % (n_a, n_b),
-            "ms_per_iteration": 1e3 * slope, "fixed_ms_per_call": 1e3 * ((t2 - t1) - n_a * slope),
-            "calls_ms": [1e3 * (t2 - t1), 1e3 * (t3 - t2)]}
+            "ms_per_iteration": 1e3 * slope, "fixed_ms_per_call": 1e3 * (median(short_calls) - 2 * slope),
+            "fixed_ms_per_call_is": "median of 3 calls of 2 outer iterations, minus 2 iterations: 268 MB in and 134 MB out of "
+                                    "pageable host memory through the copy lanes (csrc/ctx.hip stage_copy) + the Python mirror",
+            "intercept_of_the_two_call_lengths_ms": 1e3 * ((t2 - t1) - n_a * slope),
+            "calls_ms": [1e3 * (t2 - t1), 1e3 * (t3 - t2)], "short_calls_ms": [1e3 * t for t in short_calls]}
         del ys, xs
     except Exception as e:               # the group path must not take the headline line down with it
         out["group_2_virtual_shards_4x2048"] = {"error": str(e)}
 
     e = sapg("laplace", 1024, 8, False)
+    ctx.set_lanes(1)
+    e1 = sapg("laplace", 1024, 8, False)
+    ctx.set_lanes(0)
     out["sapg_laplace_8x1024"] = {"workload": "SAPG_algorithm_laplace, chambolleit 25, 8 independent 1024x1024 images in one "
                                               "call = one GPU's share of the 64 of configs[3], device Philox noise",
                                   "value": 8 * iters / e, "unit": "image-iterations/s", "steps": iters,
-                                  "ms_per_iteration": 1e3 * e / iters}
+                                  "ms_per_iteration": 1e3 * e / iters, "value_is": "two lanes (the default)",
+                                  "one_stream": 8 * iters / e1, "roofline": config_roofline("4", 8 * iters / e)}
     e = sapg("gaussian", 2048, 4, True)
+    ctx.set_lanes(2)                      # the chains split 2 + 2 over the lanes, six gradient sums exchanged in-stream
+    e2 = sapg("gaussian", 2048, 4, True)
+    ctx.set_lanes(0)
     out["sapg_gaussian_4_shared_chains_2048"] = {
         "workload": "SAPG_algorithm_Guassian, 4 MYULA chains on one 2048x2048 image with chain-averaged gradients = one "
                     "GPU's share of the 32 of configs[4] (fix_w1 = fix_w2 = 1 as run_Gaussian_demo.m:42-43), device "
                     "Philox noise", "value": 4 * iters / e, "unit": "chain-iterations/s", "steps": iters,
-        "ms_per_iteration": 1e3 * e / iters}
+        "ms_per_iteration": 1e3 * e / iters, "value_is": "one stream (the default for chains that exchange gradients)",
+        "split_over_two_lanes": 4 * iters / e2, "roofline": config_roofline("5", 4 * iters / e)}
+    # the SAPG loop of the demos themselves (run_Gaussian_demo.m:47-50,199: 15 000 warm-up + 20 000 iterations on the
+    # 512 x 512 wheel.png, PSF fixed): 2 000 iterations of it here, the whole 35 000 in profiles/r04_demo_wheel512_*.log
+    wheel = np.load(os.path.join(ROOT, "tests", "golden", "wheel_512.npy")).astype(np.float64)
+    n_demo = 2000
+    e = sapg("gaussian", 512, 1, False, its=n_demo, img=wheel)
+    out["sapg_demo_512"] = {"workload": "SAPG_algorithm_Guassian as run_Gaussian_demo.m:199 runs it: ONE chain on the 512x512 "
+                                        "wheel.png, chambolleit 25, fix_w1 = fix_w2 = 1, device Philox noise, device-resident "
+                                        "parameter loop", "value": n_demo / e, "unit": "SAPG iterations/s", "steps": n_demo,
+                            "ms_per_iteration": 1e3 * e / n_demo, "roofline": config_roofline("6", n_demo / e),
+                            "whole_demo_logs": "profiles/r04_demo_wheel512_{gaussian,moffat,laplace}.log"}
     return out
 
 
@@ -568,16 +645,28 @@ def main():
     # natural unit when many images share a GPU); reported as image-iterations/s, never as `value`
     batched = None
     if rank == 0 and world == 1 and not args.no_batched:
-        nb, ksteps = 4, max(20, args.steps // 4)
+        nb, ksteps = 4, max(100, args.steps // 4)
         yb = sbtv.to_device(np.stack([y] * nb), dev)          # column-major image memory per image
         xb = sbtv.to_device(np.stack([x] * nb), dev)
-        solve(3, -1.0, yb, xb)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        solve(ksteps, -1.0, yb, xb)
-        torch.cuda.synchronize()
-        batched = {"images_per_call": nb, "steps": ksteps, "unit": "image-iterations/s",
-                   "value": nb * ksteps / (time.perf_counter() - tb)}
+
+        def batch_rate(reps=3):
+            solve(10, -1.0, yb, xb)
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                solve(ksteps, -1.0, yb, xb)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - tb)
+            return [nb * ksteps / t for t in ts]
+        two = batch_rate()                                    # default: the batch dealt to the context's two lanes
+        ctx.set_lanes(1)
+        one = batch_rate()                                    # one stream, as before round 4
+        ctx.set_lanes(0)
+        batched = {"images_per_call": nb, "steps": ksteps, "unit": "image-iterations/s", "value": median(two),
+                   "value_is": "median of 3 calls; two lanes (include/sbtv.h sbtv_ctx_set_lanes, the default)",
+                   "samples": two, "one_stream": {"value": median(one), "samples": one},
+                   "step_roofline_frac": median(two) * model_step_bytes(SIZE) / 1e9 / HBM_PEAK_GBS}
         del yb, xb
 
     if rank == 0:

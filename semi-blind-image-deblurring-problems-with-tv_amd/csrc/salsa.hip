@@ -404,7 +404,9 @@ int sbtv_SALSA_v2(sbtv_ctx *ctx, const double *y, int M, int N, int batch, const
         const bool spec = spec_ok && outer >= 2;
         // the prox is bracketed by events on every 32nd iteration only: an event record leaves the stream idle for
         // 5-6 us; sbtv_last_timing scales the sampled time to all iterations
-        const bool timed = eager && ((outer & 31) == 4);     // (4, 36, 68, ...: warm-started proxes; the first one launched starts cold)
+        // (4, 12, 36, 68, ...: warm-started proxes; the first one launched starts cold.  Iteration 12 as well, so that a
+        // 20-step call - what the driver times - rests on two samples, not one)
+        const bool timed = eager && ((outer & 31) == 4 || outer == 12);
         slot_tagged[slot] = tagged;
         slot_spec[slot] = spec;
         double *xn = (direct_last && outer == maxiter) ? x_out : xbuf[slot];

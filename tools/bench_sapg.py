@@ -4,6 +4,7 @@
   python tools/bench_sapg.py --config 4   # 8 independent 1024x1024 images, Laplace PSF (one GPU's share of 64)
   python tools/bench_sapg.py --config 5   # 4 MYULA chains on one 2048x2048 image, Gaussian PSF (share of 32)
   python tools/bench_sapg.py --config 3   # FISTA + TV prox, 2048x2048, Moffat PSF
+  python tools/bench_sapg.py --config 6   # the demo's own SAPG loop: one chain, 512x512 wheel.png, Gaussian PSF fixed
 
 Under torch.distributed.run the same script runs the whole configuration, one rank per GPU:
   config 4: 64 images sharded over the ranks (image i -> rank i mod world), no data-path collective;
@@ -48,8 +49,8 @@ import numpy as np
 import sbtv
 
 
-def image(size, seed=0):
-    man = np.load(os.path.join(ROOT, "tests", "golden", "man_512.npy")).astype(np.float64)
+def image(size, seed=0, name="man_512.npy"):
+    man = np.load(os.path.join(ROOT, "tests", "golden", name)).astype(np.float64)
     r = max(1, size // 512)
     return np.tile(man, (r, r))[:size, :size]
 
@@ -111,11 +112,14 @@ def main():
         kind, size, share = "laplace", 1024, False
         total = a.total or (64 if world > 1 else 8)
         nimg, first = len(sd.shard(total)), 0
+    elif a.config == 6:
+        # the demo's own shape (run_Gaussian_demo.m:199): ONE chain on the 512 x 512 wheel.png, PSF fixed (fix_w1 = fix_w2 = 1)
+        kind, size, share, total, nimg, first = "gaussian", 512, False, 1, 1, 0
     else:
         kind, size, share = "gaussian", 2048, True
         total = a.total or (32 if world > 1 else 4)
         nimg, first = sd.split_chains(total)
-    x = image(size)
+    x = image(size, name="wheel_512.npy" if a.config == 6 else "man_512.npy")
     st = sbtv.demo_setup(kind, x, rng.standard_normal(x.shape), evMax=0.99, ctx=ctx)
     samples, warmup = a.iters + 1, 0
     op, c = op_struct(kind, st, samples, warmup, 2)
@@ -170,6 +174,8 @@ def main():
         print(json.dumps({
             "metric": ("SAPG chain-iterations/s, 32 MYULA chains with shared gradients on one 2048x2048 image "
                        "(BASELINE configs[4])" if share else
+                       "SAPG iterations/s, one chain on 512x512 wheel.png, Gaussian PSF fixed (run_Gaussian_demo.m:199)"
+                       if a.config == 6 else
                        "SAPG image-iterations/s, batch of 64 independent 1024x1024 images, Laplace PSF "
                        "(BASELINE configs[3])"),
             "value": total * it / dt, "unit": ("chain" if share else "image") + "-iterations/s", "n_gpus": world,
