@@ -599,7 +599,7 @@ int sbtv_diag_switches(char *buf, size_t cap) {
         "SBTV_CANARY", "SBTV_COLLECT_RIDE", "SBTV_EXACT", "SBTV_FFT_WAVE", "SBTV_FISTA_FUSED_STEP", "SBTV_FISTA_LAG",
         "SBTV_FUSED_VARIANT", "SBTV_GRAPH", "SBTV_INLINE_CTRL", "SBTV_PROX_SPEC", "SBTV_SAPG_DEFER",
         "SBTV_SAPG_FUSED_MYULA", "SBTV_SAPG_HOST", "SBTV_SINGLE_STEP", "SBTV_SPIN", "SBTV_TAG_SPIN_US", "SBTV_TILE_ORDER", "SBTV_ADMM_EXACT", "SBTV_SALSA_NOX", "SBTV_CSALSA_SPECTRAL",
-        "SBTV_CORAL_BATCH", "SBTV_ROWS_FOLD", "SBTV_ERR_SUBSET", "SBTV_LANES", "SBTV_LANE_COUNT", "SBTV_STAGE_THREADS", "SBTV_TEST_FAIL_SAPG"};
+        "SBTV_CORAL_BATCH", "SBTV_ROWS_FOLD", "SBTV_ERR_SUBSET", "SBTV_LANES", "SBTV_LANE_COUNT", "SBTV_STAGE_THREADS", "SBTV_TEST_FAIL_SAPG", "SBTV_FUSED_STAGGER"};
     // variants that lost their measurements: only the lab build (make lab, -DSBTV_LAB) carries the kernels and reads these
     static const char *const lab_names[] = {"SBTV_PROX_PIPE", "SBTV_ROWS_KERNEL", "SBTV_ROWS_PIPE", "SBTV_ROWS_RK", "SBTV_ROWS_SUB", "SBTV_TAIL_HALF", "SBTV_TAIL_ROWS",
                                             "SBTV_ROWS_V", "SBTV_U_TILED"};

@@ -13,6 +13,7 @@
 // differences of u are read back from LDS.
 #include <mutex>
 
+#include <algorithm>
 #include "sbtv_internal.h"
 
 #pragma clang fp contract(off)
@@ -234,7 +235,20 @@ constexpr int F1CI = F1RI - F1HT - F1HB; // core rows (53)
 // mixed launch of the 128-row kernel: its last workgroups work on 64-row tiles (see prox_plan)
 struct FusedMix {
     int nfull, nhi, row0;                // 128-row tiles (ids below nfull), tile rows of the 64-row part, its first image row
+    int stagger;                         // half-microseconds the second workgroup of every CU waits at the start of a launch
 };
+// Stagger (round 4, profiles/r04_chambolle_stagger.md): the 512 workgroups of the first round start together, so the two
+// workgroups of a CU wait for their regions at the same time and then share the vector units at the same time.  Holding
+// workgroups 256..511 (the second one of every CU) back by 3 us lets one of them load while the other iterates: -3 % time per
+// Chambolle iteration in the loop, +1.5 % SALSA outer iterations/s at 2048^2, same bits.  Only for grids of at least three
+// rounds (a one-round grid would just end 3 us later); SBTV_FUSED_STAGGER=n: n half-microseconds, 0 = off.
+static int fused_stagger(int nblk) {
+    static const int v = [] {
+        const char *e = getenv("SBTV_FUSED_STAGGER");
+        return e ? atoi(e) : 6;
+    }();
+    return nblk >= 3 * 256 ? v : 0;
+}
 // tuning parameters: columns per wave (cj) and waves per block (nw): region columns = nw*cj,
 // core columns = nw*cj - 2 FHJ; minw = waves per SIMD requested from the register allocator
 struct FusedVariant { int cj; int nw; int minw; int fast; int rpl; };   // rpl = rows per lane (2: tv_fused.inc, 1: tv_fused1.inc)
@@ -864,11 +878,22 @@ int prox_plan(sbtv_ctx *ctx, int M, int N, int batch, ProxPlan *pl, const char *
                     int len = fq8 + (x < fr8 ? 1 : 0);
                     if (len > cnt) len = cnt;
                     int o = 0;
+                    // experiment (SBTV_TILE_ORDER=2 / 3): inside a chunk walk the tiles ROW by row (horizontal neighbours, which
+                    // share 11 of their 32 region columns, become consecutive workgroups of the XCD; by default vertical
+                    // neighbours are, which share 12 of 128 rows); 3: the same without the border-first pass
+                    static const int env_mode = [] {
+                        const char *e = getenv("SBTV_TILE_ORDER");
+                        return e ? atoi(e) : 1;
+                    }();
+                    std::vector<int> chunk;
+                    for (int t2 = c0; t2 < c0 + len; ++t2) chunk.push_back(t2);
+                    if (env_mode >= 2)
+                        std::stable_sort(chunk.begin(), chunk.end(), [&](int a, int b2) { return (a % ti_n) < (b2 % ti_n); });
                     for (int pass = 0; pass < 2; ++pass)
-                        for (int t2 = c0; t2 < c0 + len; ++t2) {
+                        for (int t2 : chunk) {
                             const int ti = t2 % ti_n, tj = t2 / ti_n;
                             const bool border = (ti == 0 || (!pl->mix_nfull && ti == ti_n - 1) || tj == 0 || tj == tj_n - 1);
-                            if (border == (pass == 0)) h[(size_t)(o++) * 8 + x] = t2;      // workgroup id = o * 8 + x
+                            if (env_mode == 3 ? (pass == 0) : (border == (pass == 0))) h[(size_t)(o++) * 8 + x] = t2;      // workgroup id = o * 8 + x
                         }
                     while (o < cnt) h[(size_t)(o++) * 8 + x] = half_next++;
                 }
@@ -1021,11 +1046,11 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
         if (g_fused.fast)                                                                                            \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, true>), fgrid, dim3(64 * NW_), 0, ctx->stream, \
                                g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, \
-                               redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0});  \
+                               redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0, fused_stagger(pl.fnblk)});  \
         else                                                                                                         \
             hipLaunchKernelGGL((chambolle_fused_kernel<CJ_, NW_, MW_, false>), fgrid, dim3(64 * NW_), 0,             \
                                ctx->stream, g, pl.pbuf, pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i,     \
-                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0}); \
+                               pl.fnblk, steps, redo, f_out, write_f, pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0, fused_stagger(pl.fnblk)}); \
     }
             // optimistic ping-pong launches of a solver loop (spec == 1: the caller only CHECKS the rule afterwards): the error
             // sums run over a quarter of the columns (tv_fused.inc, ESUB); SBTV_ERR_SUBSET=0: all columns
@@ -1038,13 +1063,13 @@ int prox_iterate(sbtv_ctx *ctx, const ProxPlan &pl, const double *g, int maxiter
                 launched = true;
                 hipLaunchKernelGGL((chambolle_fused_kernel<4, 8, 4, true, false, true>), fgrid, dim3(64 * 8), 0, ctx->stream, g, pl.pbuf,
                                    pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.ftiles_i, pl.fnblk, steps, redo, f_out, write_f,
-                                   pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0});
+                                   pl.counters, kflags, sj, pl.order, FusedMix{0, 0, 0, fused_stagger(pl.fnblk)});
             } else
 #ifdef SBTV_LAB
             if (!pl.pipe && pl.rpl == 2 && pl.mix_nfull > 0) {
                 // mixed tiling (shipped geometry only, see prox_plan): the 128-row grid has mix_nfi tile rows
                 launched = true;
-                const FusedMix mix{pl.mix_nfull, pl.mix_nhi, pl.mix_row0};
+                const FusedMix mix{pl.mix_nfull, pl.mix_nhi, pl.mix_row0, 0};
                 if (g_fused.fast)
                     hipLaunchKernelGGL((chambolle_fused_kernel<4, 8, 4, true, true>), fgrid, dim3(64 * 8), 0, ctx->stream, g, pl.pbuf,
                                        pl.ctrl, pl.partials, pl.M, pl.N, pl.batch, pl.mix_nfi, pl.fnblk, steps, redo, f_out, write_f,
