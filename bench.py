@@ -545,6 +545,59 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def group_mode(args):
+    """`--group`: ONE process, `sbtv.Group(range(N))`, one image per device through sbtv_SALSA_v2_sharded_dev (device-resident
+    images, one host thread per device inside the library, no torch.distributed, no RCCL) - the path a single MATLAB / C host
+    takes to a whole node.  Same problem, same pre-roll and the same timed call length as the multi-process mode, so that the
+    two can be compared the day a multi-GPU node runs them.  `--all-ranks-on-device0` puts every shard on GPU 0 (rehearsal)."""
+    import numpy as np
+    import torch
+    import sbtv
+    n = max(1, args.gpus)
+    devices = [0] * n if args.all_ranks_on_device0 else list(range(n))
+    g = sbtv.Group(devices)
+    probs = [make_problem(seed=1 + r) for r in range(n)]
+    ys = [sbtv.to_device(p[1][None], f"cuda:{d}") for p, d in zip(probs, devices)]
+    xs = [sbtv.to_device(p[0][None], f"cuda:{d}") for p, d in zip(probs, devices)]
+    taps = sbtv.Gaussian_psf(7, *W_TRUE)
+    mu = THETA / 10
+    taus = [THETA * p[2] ** 2 for p in probs]
+    solve = lambda k, tol: g.SALSA_v2_device(ys, taps, taus, mu, k, 10, tol, 1, xs)
+    xg, obj, n_out = solve(500, 1e-5)
+    import gc
+    gc.collect()
+    gc.disable()
+    solve(300, -1.0)
+    if args.warmup > 0:
+        solve(args.warmup, -1.0)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    _, obj_t, n_t = solve(args.steps, -1.0)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    assert all(int(k) == args.steps for k in n_t)
+    psnr0 = psnr(probs[0][0], sbtv.to_host(xg[0])[0])
+    virtual = len(set(devices)) < n
+    line = {"metric": "SALSA outer-iters/sec + final PSNR, 2048x2048 Gaussian blur", "value": n * args.steps / elapsed,
+            "unit": "SALSA outer-iterations/s", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SALSA_v2 TV deblur (TViters=10, mu=theta/10, tau=theta*sigma^2, theta=0.03), one 2048x2048 "
+                                   "image per shard, device-resident", "image": [SIZE, SIZE], "shards": n, "devices": devices,
+                       "parallelism": f"single process, sbtv_group of {n} contexts (one host thread per shard, no RCCL)"},
+            "mode": "group", "virtual_shards_on_one_gpu": virtual,
+            "measured_on_multi_gpu_hardware": (not virtual) and n > 1,
+            "final_psnr_db": psnr0, "outer_iterations_to_tol_1e-5": int(n_out[0]),
+            "psnr_matches_fixture": fixture_check("salsa2048", psnr0, int(n_out[0])),
+            "pre_roll_steps": {"converged_solve": int(n_out[0]), "clock_rampup": 300, "warmup": args.warmup},
+            "switches": sbtv.switches()}
+    print(json.dumps(line), flush=True)
+    g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -559,7 +612,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--dry-run", action="store_true", help="launch path only: rendezvous, barrier, one JSON line")
+    ap.add_argument("--group", action="store_true", help="single process: one sbtv.Group over --gpus devices (sbtv_SALSA_v2_sharded_dev)")
     args = ap.parse_args()
+    if args.group:
+        return group_mode(args)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))        # before anything imports torch / touches the GPU

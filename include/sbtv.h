@@ -381,6 +381,14 @@ int sbtv_SALSA_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
                           const sbtv_salsa_opts *opts, const double *true_x, const double *x_init,
                           double *x_out, double *objective, double *distance, double *times, double *mses,
                           int *numA, int *numAt, int *n_outer);
+/* device-resident variant: y[r] / true_x[r] / x_init[r] / x_out[r] (r < min(n, n_items)) are DEVICE pointers on shard r's
+ * device to that shard's block of images (sbtv_group_shard_of: first, count), laid out as for sbtv_SALSA_v2 with
+ * SBTV_DEVICE_PTRS; true_x and x_init may be NULL.  Nothing is copied between host and devices. */
+int sbtv_SALSA_v2_sharded_dev(sbtv_group *g, const double *const *y, int M, int N, int n_items,
+                              const double *taps, int taille, const double *tau, const double *mu,
+                              const sbtv_salsa_opts *opts, const double *const *true_x,
+                              const double *const *x_init, double *const *x_out, double *objective,
+                              double *distance, double *times, double *mses, int *numA, int *numAt, int *n_outer);
 int sbtv_SAPG_algorithm_sharded(sbtv_group *g, const double *y, int M, int N, int n_items,
                                 const sbtv_sapg_opts *op, const double *x0, const double *noise,
                                 double *thetas, double *ps, double *sigmas, double *logpi,
@@ -438,6 +446,9 @@ int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
  *   only when the solve ran to MAXITERA).
  * sbtv_diag_switches: the SBTV_* environment switches that are set in this process, as "NAME=value ..." (returns their
  *   number; 0 and an empty string = the default kernels).  They are tuning / A-B hooks, read once per process. */
+/* Layout helper for row-major hosts (NumPy, C; MATLAB needs none): dst[b][c][r] = src[b][r][c] for `batch` images of
+ * rows x cols doubles - row-major images -> the column-major images every entry point takes, and back with rows / cols swapped. */
+int sbtv_host_transpose(const double *src, double *dst, int batch, int rows, int cols);
 int sbtv_diag_solve_stats(const sbtv_ctx *ctx, double out[4]);
 int sbtv_diag_stage_stats(const sbtv_ctx *ctx, double out[4]);
 int sbtv_diag_canary(sbtv_ctx *ctx, int poke, int *enabled, int *nbuf, int *nbad);

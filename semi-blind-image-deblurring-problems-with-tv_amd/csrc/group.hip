@@ -289,6 +289,35 @@ int sbtv_CoRAL_v2_sharded(sbtv_group *g, const double *y, int M, int N, int n_it
                          objective, distance, times, mses, numA, numAt, n_outer, SBTV_HOST_PTRS);
 }
 
+// Device-resident images on several GPUs: y[r] (true_x[r], x_init[r], x_out[r]) is a DEVICE pointer on shard r's device to
+// that shard's block of images (sbtv_group_shard_of gives first / count), column-major, one after the other.
+int sbtv_SALSA_v2_sharded_dev(sbtv_group *g, const double *const *y, int M, int N, int n_items, const double *taps,
+                              int taille, const double *tau, const double *mu, const sbtv_salsa_opts *opts,
+                              const double *const *true_x, const double *const *x_init, double *const *x_out,
+                              double *objective, double *distance, double *times, double *mses, int *numA, int *numAt,
+                              int *n_outer) {
+    if (!g) return SBTV_ERR_BADARG;
+    if (!y || !tau || !mu || !opts || n_items < 1 || M < 2 || N < 2)
+        return gfail(g, SBTV_ERR_BADARG, "SALSA_v2_sharded_dev: missing required argument");
+    if (!taps) return gfail(g, SBTV_ERR_MISSING_AT, "The function handle for transpose of A is missing");
+    const int ns = std::min((int)g->ctxs.size(), n_items);
+    g->active = ns;
+    g->rv.reset(ns);
+    for (int r = 0; r < ns; ++r)
+        if (!y[r] || (x_out && !x_out[r])) return gfail(g, SBTV_ERR_BADARG, "SALSA_v2_sharded_dev: a shard's image pointer is NULL");
+    const size_t t2 = (size_t)taille * taille, K = (size_t)(opts->maxiter > 0 ? opts->maxiter : 0);
+    auto offp = [](auto *p, size_t o) { return p ? p + o : p; };
+    return run_shards(g, ns, [&](int r) -> int {
+        int lo, hi;
+        block_of(n_items, ns, r, &lo, &hi);
+        const size_t b = (size_t)lo;
+        return sbtv_SALSA_v2(g->ctxs[r], y[r], M, N, hi - lo, taps + b * t2, taille, tau + b, mu + b, opts,
+                             true_x ? true_x[r] : nullptr, x_init ? x_init[r] : nullptr, x_out ? x_out[r] : nullptr,
+                             offp(objective, b * (K + 1)), offp(distance, b * K), offp(times, b * (K + 1)), offp(mses, b * (K + 1)),
+                             offp(numA, b), offp(numAt, b), offp(n_outer, b), SBTV_DEVICE_PTRS);
+    });
+}
+
 int sbtv_ctx_set_lanes(sbtv_ctx *ctx, int mode) {
     if (!ctx || mode < 0 || mode > 2) return SBTV_ERR_BADARG;
     ctx->lanes_mode = mode;

@@ -115,6 +115,8 @@ SIGNATURES = {
     "sbtv_group_shard_of": (_I, [_P, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_SALSA_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.POINTER(sbtv_salsa_opts), _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _P]),
+    "sbtv_SALSA_v2_sharded_dev": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.POINTER(sbtv_salsa_opts), _P, _P, _P, _P, _P,
+                                       _P, _P, _P, _P, _P]),
     "sbtv_SAPG_algorithm_sharded": (_I, [_P, _P, _I, _I, _I, C.POINTER(sbtv_sapg_opts), _P, _P, _P, _P, _P, _P, _P, _P,
                                          _P, _P, _P]),
     "sbtv_fista_tv_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _D, _I, _I, _D, _I, _I, _P, _P, _P, _P, _P]),
@@ -123,6 +125,7 @@ SIGNATURES = {
     "sbtv_CoRAL_v2_sharded": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, C.POINTER(sbtv_salsa_opts), _P,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sbtv_diag_stage_stats": (_I, [_P, C.POINTER(_D)]),
+    "sbtv_host_transpose": (_I, [_P, _P, _I, _I, _I]),
     "sbtv_diag_solve_stats": (_I, [_P, C.POINTER(_D)]),
     "sbtv_diag_canary": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "sbtv_diag_prox_variant": (_I, [_P, _I, _I, _I, C.POINTER(_I)]),
@@ -309,6 +312,51 @@ class Group:
         if rc != 0:
             raise SbtvError(rc, self.lib.sbtv_group_last_error(self.h).decode())
 
+    def blocks(self, n_items):
+        """[(first, count)] of the shards that take part in a call with n_items items."""
+        out, i = [], 0
+        while i < n_items:
+            s = self.shard_of(n_items, i)
+            out.append((s["first"], s["count"]))
+            i = s["first"] + s["count"]
+        return out
+
+    def SALSA_v2_device(self, y_shards, taps, tau, mu, maxiter, TViters=10, tolA=1e-3, stopcriterion=1, true_shards=None):
+        """sbtv_SALSA_v2_sharded_dev: `y_shards[r]` is a float64 torch tensor ON shard r's device holding that shard's block
+        of images (count_r, M, N), column-major image memory (sbtv.to_device); n_items = sum of the counts, dealt as
+        `blocks(n_items)` says.  taps: (taille, taille) PSF for all images; tau, mu: scalars or per-image sequences.
+        Returns (x_shards, objective[n_items][...], n_outer): nothing crosses the host."""
+        import torch
+        ys = [Images(t) for t in y_shards]
+        n_items = sum(i.B for i in ys)
+        blk = self.blocks(n_items)
+        if [i.B for i in ys] != [c for _, c in blk]:
+            raise ValueError(f"shard r must hold the images of its block: counts {[c for _, c in blk]}")
+        M, N = ys[0].M, ys[0].N
+        ts = [Images(t) for t in true_shards] if true_shards is not None else None
+        xs = [empty_like_images(i) for i in ys]
+        for t in y_shards:
+            torch.cuda.synchronize(t.device)
+        so = sbtv_salsa_opts()
+        self.lib.sbtv_salsa_opts_default(C.byref(so))
+        so.stopcriterion, so.maxiter, so.TViters, so.tolA = int(stopcriterion), int(maxiter), int(TViters), float(tolA)
+        so.compute_mse = 1 if ts is not None else 0
+        K = so.maxiter
+        objective = np.zeros((n_items, K + 1)); distance = np.zeros((n_items, K)); times = np.zeros((n_items, K + 1))
+        mses = np.zeros((n_items, K + 1))
+        nA, nAt, nout = (C.c_int * n_items)(), (C.c_int * n_items)(), (C.c_int * n_items)()
+        tp = np.ascontiguousarray(np.broadcast_to(np.asarray(taps, dtype=np.float64).T, (n_items,) + np.shape(taps)[::-1]))
+        tau_a, tau_p = dvec(tau, n_items)
+        mu_a, mu_p = dvec(mu, n_items)
+        arr = lambda imgs: (C.c_void_p * len(imgs))(*[i.ptr.value for i in imgs])
+        ya, xa = arr(ys), arr(xs)
+        ta = arr(ts) if ts is not None else None
+        self.check(self.lib.sbtv_SALSA_v2_sharded_dev(self.h, ya, M, N, n_items, vptr(tp), int(np.shape(taps)[0]), tau_p, mu_p,
+                                                      C.byref(so), ta, None, xa, vptr(objective), vptr(distance), vptr(times),
+                                                      vptr(mses) if ts is not None else None, nA, nAt, nout))
+        n = np.array(nout[:])
+        return [x.t for x in xs], [objective[b, :n[b] + 1].copy() for b in range(n_items)], n
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.sbtv_group_destroy(self.h)
@@ -344,6 +392,21 @@ def default_context(device=None) -> Context:
 # ---------------------------------------------------------------------------
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
+
+
+def column_major_images(a):
+    """(B, M, N) float64 array in any layout -> C-contiguous (B, N, M) array = column-major images.  Arrays that already are
+    column-major per image (Fortran-ordered images, e.g. what `images_result` returns) pass through without a copy; C-ordered
+    ones go through the library's blocked, threaded transpose (numpy's strided copy is ~40 x slower)."""
+    t = np.transpose(a, (0, 2, 1))
+    if t.flags.c_contiguous:
+        return t
+    if a.flags.c_contiguous and a.size >= 4096:
+        out = np.empty((a.shape[0], a.shape[2], a.shape[1]), dtype=np.float64)
+        rc = load_library().sbtv_host_transpose(vptr(a), vptr(out), a.shape[0], a.shape[1], a.shape[2])
+        if rc == 0:
+            return out
+    return np.ascontiguousarray(t)
 
 
 class Images:
@@ -383,7 +446,7 @@ class Images:
             if a.ndim != 3:
                 raise ValueError("images must be (M,N) or (B,M,N)")
             self.B, self.M, self.N = a.shape
-            self.buf = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))   # (B,N,M): column-major images
+            self.buf = column_major_images(a)                             # (B,N,M): column-major images
             self.ptr = vptr(self.buf)
             self.flags = SBTV_HOST_PTRS
 
@@ -423,7 +486,7 @@ def to_device(x, device="cuda:0"):
     sq = a.ndim == 2
     if sq:
         a = a[None]
-    t = torch.from_numpy(np.ascontiguousarray(np.transpose(a, (0, 2, 1)))).to(device).permute(0, 2, 1)
+    t = torch.from_numpy(np.ascontiguousarray(column_major_images(a))).to(device).permute(0, 2, 1)
     return t[0] if sq else t
 
 

@@ -140,7 +140,7 @@ def _sapg(kind, y, op, c, noise=None, x0=None, share_gradients=False, reduce_fn=
             a = np.asarray(noise, dtype=np.float64)           # (steps, B, M, N) or (steps, M, N)
             if a.ndim == 3:
                 a = a[:, None]
-            nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))     # column-major images
+            nz_keep = L.column_major_images(a.reshape((-1,) + a.shape[2:])).reshape(a.shape[:2] + (a.shape[3], a.shape[2]))   # column-major images
             nz_ptr = L.vptr(nz_keep)
     cb = L.ALLREDUCE_FN(reduce_fn) if reduce_fn is not None else L.ALLREDUCE_FN()
     xflags = L.SAPG_HOST_LOOP if host_loop else 0
@@ -293,7 +293,7 @@ def myula(op, im=None, noise=None, ctx=None):
             a = np.asarray(noise, dtype=np.float64)
             if a.ndim == 3:
                 a = a[:, None]
-            nz_keep = np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2)))
+            nz_keep = L.column_major_images(a.reshape((-1,) + a.shape[2:])).reshape(a.shape[:2] + (a.shape[3], a.shape[2]))
             nz_ptr = L.vptr(nz_keep)
     ctx.check(ctx.lib.sbtv_myula(ctx.h, yi.ptr, M, N, B, L.vptr(taps), A.taille,
                                  float(_get(op, "lambda")), float(_get(op, "gamma")), keep[0][1], keep[1][1],

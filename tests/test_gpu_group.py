@@ -215,3 +215,45 @@ def test_group_on_two_physical_devices_salsa_and_shared_chains(ctx):
                 np.testing.assert_allclose(got[k][key], ref[k][key], rtol=1e-11, err_msg=f"{k}:{key}")
     finally:
         g.close()
+
+
+def test_salsa_sharded_device_resident_blocks_bit_equal(ctx):
+    """sbtv_SALSA_v2_sharded_dev: every shard's block of images already lives on its device (torch tensors); bit-equal to the
+    single-context device-resident batch, nothing staged through the host."""
+    import sbtv
+    g = sbtv.Group([0, 0])
+    try:
+        xs, ys, taus = _salsa_problem(3, 128, 128)
+        taps = sbtv.Gaussian_psf(7, 0.4, 0.3)
+        A = sbtv.BlurOperator(taps)
+        one = sbtv.SALSA_v2(sbtv.to_device(ys), A, taus, "MU", 0.003, "AT", A.T, "LS", A.LS(0.003), "True_x", sbtv.to_device(xs),
+                            "ToleranceA", 1e-4, "MAXITERA", 60, "TVINITIALIZATION", 1, "TViters", 10, ctx=ctx)
+        blk = g.blocks(3)
+        assert blk == [(0, 2), (2, 1)]
+        ysh = [sbtv.to_device(ys[f:f + c]) for f, c in blk]
+        xsh = [sbtv.to_device(xs[f:f + c]) for f, c in blk]
+        x_sh, obj, n = g.SALSA_v2_device(ysh, taps, taus, 0.003, 60, 10, 1e-4, 1, xsh)
+        got = np.concatenate([sbtv.to_host(t) for t in x_sh])
+        np.testing.assert_array_equal(got, sbtv.to_host(one[0]))
+        for b in range(3):
+            np.testing.assert_array_equal(obj[b], one[3][b])
+        with pytest.raises(ValueError):
+            g.SALSA_v2_device([ysh[1], ysh[0]], taps, taus, 0.003, 5)         # blocks in the wrong shards
+    finally:
+        g.close()
+
+
+def test_bench_group_mode_rehearsal_on_virtual_shards():
+    """`bench.py --group --gpus 2 --all-ranks-on-device0`: the single-process multi-device bench path (one sbtv.Group, device-
+    resident images, sbtv_SALSA_v2_sharded_dev) end to end on this box's one GPU.  Unmeasured on multi-GPU hardware."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--group", "--gpus", "2", "--all-ranks-on-device0",
+                        "--steps", "12", "--warmup", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["mode"] == "group" and line["config"]["shards"] == 2 and line["virtual_shards_on_one_gpu"] is True
+    assert line["measured_on_multi_gpu_hardware"] is False and line["steps"] == 12 and line["value"] > 100
+    assert line["psnr_matches_fixture"]["matches"] is True
