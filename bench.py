@@ -350,15 +350,15 @@ CONFIGS_FILE = os.path.join(ROOT, "profiles", "configs_current.json")
 CONFIG_MODELS = {
     # my_fista iteration (SALSA/my_fista.m:22-33): cols(y) 16 + rows GRADF 32 + cols^-1 with the gradient step 24 + prox 192
     # + momentum (x, x_old, true in, y out) 32 + objective: cols(x) 16 + residual rows (S, H, Y in) 24
-    "3": dict(bytes_per_px=336.0, px=2048 * 2048, unit="FISTA iteration"),
+    "3": dict(bytes_per_px=336.0, px=2048 * 2048, unit="FISTA iteration", units_per_iteration=1),
     # SAPG Laplace image-iteration, PSF moving: tap + derivative spectra written 16, rows GRADF 32, cols^-1 + MYULA step 32,
     # prox 192, cols(X) 16, gradient-sums rows (S, H, Y, D in) 32
-    "4": dict(bytes_per_px=320.0, px=1024 * 1024, unit="image-iteration"),
+    "4": dict(bytes_per_px=320.0, px=1024 * 1024, unit="image-iteration", units_per_iteration=8),
     # SAPG Gaussian chain-iteration, PSF fixed, 4 chains share the operator spectra (read once per row block for all
     # chains: 32 / 4): cols^-1 + MYULA 32, prox 192, cols(X) 16, rows GRAD with inverse 16 + 8
-    "5": dict(bytes_per_px=264.0, px=2048 * 2048, unit="chain-iteration"),
+    "5": dict(bytes_per_px=264.0, px=2048 * 2048, unit="chain-iteration", units_per_iteration=4),
     # the demo's loop at 512^2 (fixed PSF, one chain): same passes, spectra not shared
-    "6": dict(bytes_per_px=288.0, px=512 * 512, unit="iteration"),
+    "6": dict(bytes_per_px=288.0, px=512 * 512, unit="iteration", units_per_iteration=1),
 }
 
 
@@ -377,10 +377,10 @@ def config_roofline(cfg, units_per_s):
             return r
         c = d["configs"][cfg]
         r["pmc_file"] = "ok"
-        r["traffic"] = c["hbm_bytes_per_iteration"]
-        r["traffic_is"] = "PMC bytes of ONE iteration of all local units in the profiled run (%s)" % c["tag"]
-        r["profiled_us_per_iteration"] = c["us_per_iteration"]
-        r["traffic_frac"] = c["hbm_bytes_per_iteration"] / (c["us_per_iteration"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        r["traffic"] = c["hbm_bytes_per_iteration"] / m["units_per_iteration"]
+        r["traffic_is"] = "PMC bytes per %s (2 x FETCH_SIZE + WRITE_SIZE over the launches of one iteration of the profiled run %s)" % (m["unit"], c["tag"])
+        # like `frac`: against THIS run's rate (a rate taken under the profiler is not a measurement of speed)
+        r["traffic_frac"] = r["traffic"] * units_per_s / 1e9 / HBM_PEAK_GBS
         r["dominant_kernel"] = c["dominant_kernel"]
         r["dominant_kernel_share_of_gpu_time"] = c["dominant_kernel_share"]
         r["launches_per_iteration"] = c["launches_per_iteration"]
