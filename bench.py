@@ -607,7 +607,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the auxiliary 4-image batch measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the 512x512 block and the per-pass timings")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[2..4] block")
-    ap.add_argument("--extra-iters", type=int, default=30, help="iterations per configs[2..4] measurement")
+    ap.add_argument("--extra-iters", type=int, default=60, help="iterations per configs[2..4] measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
