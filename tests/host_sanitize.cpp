@@ -126,6 +126,42 @@ int main() {
         CHECK(sbtv_SALSA_v2_sharded(nullptr, nullptr, 2, 2, 1, nullptr, 7, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == SBTV_ERR_BADARG);
     }
+    // ---- round 4: the threaded layout helper on ragged shapes (block edges, one row / one column, threads vs no threads),
+    // the new sharded entry points and diagnostics without a group / context
+    {
+        const int shapes[][3] = {{1, 1, 1}, {2, 1, 9}, {3, 65, 1}, {2, 64, 64}, {1, 130, 67}, {4, 700, 300}};
+        for (const auto &sh : shapes) {
+            const int B = sh[0], R = sh[1], Cc = sh[2];
+            std::vector<double> a((size_t)B * R * Cc), t(a.size(), -1.0), back(a.size(), -2.0);
+            for (size_t i = 0; i < a.size(); ++i) a[i] = (double)i * 0.5 - 3.0;
+            CHECK(sbtv_host_transpose(a.data(), t.data(), B, R, Cc) == 0);
+            bool ok = true;
+            for (int b = 0; b < B && ok; ++b)
+                for (int r = 0; r < R && ok; ++r)
+                    for (int c = 0; c < Cc; ++c)
+                        if (t[((size_t)b * Cc + c) * R + r] != a[((size_t)b * R + r) * Cc + c]) { ok = false; break; }
+            CHECK(ok);
+            CHECK(sbtv_host_transpose(t.data(), back.data(), B, Cc, R) == 0);
+            CHECK(back == a);
+        }
+        double d = 0.0;
+        CHECK(sbtv_host_transpose(nullptr, &d, 1, 1, 1) == SBTV_ERR_BADARG);
+        CHECK(sbtv_host_transpose(&d, &d, 1, -1, 1) == SBTV_ERR_BADARG);
+        CHECK(sbtv_host_transpose(&d, &d, 0, 5, 5) == 0);
+        double st4[4];
+        CHECK(sbtv_diag_stage_stats(nullptr, st4) == SBTV_ERR_BADARG && sbtv_diag_solve_stats(nullptr, st4) == SBTV_ERR_BADARG);
+        CHECK(sbtv_ctx_set_lanes(nullptr, 0) == SBTV_ERR_BADARG);
+        CHECK(sbtv_fista_tv_sharded(nullptr, nullptr, 2, 2, 1, nullptr, 7, nullptr, 1.0, 25, 1, 0.0, 1, 0, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr) == SBTV_ERR_BADARG);
+        CHECK(sbtv_CSALSA_v2_sharded(nullptr, nullptr, 2, 2, 1, nullptr, 7, nullptr, nullptr, nullptr, nullptr, 1.0, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr) == SBTV_ERR_BADARG);
+        CHECK(sbtv_CoRAL_v2_sharded(nullptr, nullptr, 2, 2, 1, nullptr, 7, nullptr, nullptr, nullptr, nullptr, nullptr, 5, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr) == SBTV_ERR_BADARG);
+        CHECK(sbtv_SALSA_v2_sharded_dev(nullptr, nullptr, 2, 2, 1, nullptr, 7, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == SBTV_ERR_BADARG);
+    }
     std::printf(fails ? "%d host checks FAILED\n" : "host sanitizer run: all checks passed\n", fails);
     return fails ? 1 : 0;
 }

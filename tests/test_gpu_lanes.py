@@ -184,3 +184,58 @@ def test_csalsa_and_coral_lanes_and_sharded_are_bit_equal_to_one_stream(ctx1, ct
             np.testing.assert_array_equal(got[0], one[0])
             for b in range(3):
                 np.testing.assert_array_equal(got[3][b], one[3][b])      # objective traces
+
+
+def test_lanes_stress_alternating_batches_and_entry_points(ctx1, ctx2):
+    """Forty calls on ONE pair of contexts with changing batch sizes, image sizes and entry points (the lanes' workspaces grow,
+    plans and order tables are rebuilt, host threads are started and joined every call): every result equals the one-stream
+    context's bit for bit."""
+    import sbtv
+    rng = np.random.default_rng(123)
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    for it in range(40):
+        n = int(rng.integers(2, 7))
+        M, N = [(64, 48), (128, 128), (96, 80), (256, 64)][int(rng.integers(0, 4))]
+        xs, ys, taus = _salsa_problem(n, M, N)
+        if it % 3 == 2:
+            f = lambda c: sbtv.chambolle_prox_TV_stop(ys, "lambda", 8.0, "maxiter", 12, ctx=c)       # (no lanes: a single pass)
+            a, b = f(ctx1), f(ctx2)
+            np.testing.assert_array_equal(b[0], a[0])
+            continue
+        args = ("MU", 0.003, "AT", A.T, "LS", A.LS(0.003), "True_x", xs, "ToleranceA", 1e-3, "MAXITERA", 25,
+                "TVINITIALIZATION", 1, "TViters", int(rng.integers(3, 11)))
+        one = sbtv.SALSA_v2(ys, A, taus, *args, ctx=ctx1)
+        two = sbtv.SALSA_v2(ys, A, taus, *args, ctx=ctx2)
+        np.testing.assert_array_equal(two[0], one[0], err_msg=f"call {it}: {n} x {M} x {N}")
+        for b in range(n):
+            np.testing.assert_array_equal(two[3][b], one[3][b])
+
+
+def test_two_host_threads_with_a_context_each_use_their_lanes_concurrently():
+    """Two application threads, each with its own context (four lane threads, four streams on the one GPU), solving
+    different batches at the same time: each gets the result of its solitary run."""
+    import threading
+    import sbtv
+    A = sbtv.BlurOperator(sbtv.Gaussian_psf(7, 0.4, 0.3))
+    probs = [_salsa_problem(3, 128, 128), _salsa_problem(4, 96, 80)]
+    ctxs = [sbtv.Context(0), sbtv.Context(0)]
+    try:
+        def solve(i):
+            xs, ys, taus = probs[i]
+            return sbtv.SALSA_v2(ys, A, taus, "MU", 0.003, "AT", A.T, "LS", A.LS(0.003), "True_x", xs, "ToleranceA", 1e-4,
+                                 "MAXITERA", 60, "TVINITIALIZATION", 1, "TViters", 10, ctx=ctxs[i])
+        alone = [solve(0), solve(1)]
+        got = [None, None]
+        for rep in range(3):
+            th = [threading.Thread(target=lambda i=i: got.__setitem__(i, solve(i))) for i in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for i in range(2):
+                np.testing.assert_array_equal(got[i][0], alone[i][0])
+                for b in range(len(alone[i][3])):
+                    np.testing.assert_array_equal(got[i][3][b], alone[i][3][b])
+    finally:
+        for c in ctxs:
+            c.close()
