@@ -296,9 +296,14 @@ static int stage_copy(sbtv_ctx *ctx, void *dst, const void *src, size_t bytes, b
     {
         std::vector<std::thread> th;
         const int nt = (int)std::min<size_t>((size_t)T, nchunks);
-        for (int t = 1; t < nt; ++t) th.emplace_back(lane, t);
+        int started = 1;
+        try {
+            for (int t = 1; t < nt; ++t, ++started) th.emplace_back(lane, t);
+        } catch (...) {                                                // no thread to be had: the caller's thread does the rest
+        }
         lane(0);                                                       // the calling thread is lane 0
         for (auto &x : th) x.join();
+        for (int t = started; t < nt; ++t) lane(t);                    // chunks of the lanes that could not be started
     }
     for (int t = 0; t < kStageMaxThreads; ++t)
         if (errs[t] != hipSuccess) return fail_hip(ctx, errs[t], "stage_copy", __FILE__, __LINE__);
@@ -588,9 +593,14 @@ int sbtv_host_transpose(const double *src, double *dst, int batch, int rows, int
     const size_t bytes = (size_t)batch * rows * cols * sizeof(double);
     const int T = bytes >= ((size_t)4 << 20) ? 4 : 1;
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t, T);
+    int started = 1;
+    try {
+        for (int t = 1; t < T; ++t, ++started) th.emplace_back(work, t, T);
+    } catch (...) {                                                    // no thread to be had: the caller's thread does the rest
+    }
     work(0, T);
     for (auto &x : th) x.join();
+    for (int t = started; t < T; ++t) work(t, T);
     return 0;
 }
 

@@ -150,12 +150,21 @@ static int run_shards(sbtv_group *g, int ns, F fn) {
     std::vector<int> rc(ns, 0);
     std::vector<std::thread> th;
     th.reserve(ns);
-    for (int r = 0; r < ns; ++r)
-        th.emplace_back([&, r] {
-            rc[r] = (hipSetDevice(g->devices[r]) == hipSuccess) ? fn(r) : (int)hipErrorInvalidDevice;
-            if (rc[r] != 0) g->rv.abort();          // nobody may wait for this shard any more
-        });
+    bool spawn_failed = false;
+    for (int r = 0; r < ns; ++r) {
+        try {
+            th.emplace_back([&, r] {
+                rc[r] = (hipSetDevice(g->devices[r]) == hipSuccess) ? fn(r) : (int)hipErrorInvalidDevice;
+                if (rc[r] != 0) g->rv.abort();          // nobody may wait for this shard any more
+            });
+        } catch (...) {                                 // no thread to be had: nothing may cross the C-ABI as an exception
+            spawn_failed = true;
+            g->rv.abort();                              // the shards already running must not wait for the missing ones
+            break;
+        }
+    }
     for (auto &t : th) t.join();
+    if (spawn_failed) return gfail(g, SBTV_ERR_NOMEM, "sbtv_group: cannot start a host thread per shard");
     // a shard that failed on its own is reported before one that only saw its peer fail
     for (int pass = 0; pass < 2; ++pass)
         for (int r = 0; r < ns; ++r)
