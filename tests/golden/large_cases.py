@@ -86,7 +86,13 @@ def fista2048():
 SAPG_L = dict(samples=3, warmup=2, burnIn=2, batch=8, c=dict(theta=0.01, p=(0.1,), sigma=100.0))
 
 
-def sapg_laplace_1024x8():
+# the same batch with the reference's OWN step scales (SAPG_algorithm_laplace.m:139-141): b and sigma^2 are thrown onto their
+# projection bounds by the first update, the following updates run with the projected values (round-3 review, weak #2)
+SAPG_L_REF = dict(samples=4, warmup=2, burnIn=2, batch=8, c=dict(theta=0.01, p=(100.0,), sigma=1e4))
+
+
+def sapg_laplace_1024x8(S=None):
+    S = S or SAPG_L
     o = _oracle()
     x0 = tiled(1024)
     rng = np.random.default_rng(4)
@@ -97,8 +103,8 @@ def sapg_laplace_1024x8():
     for st in sts[1:]:
         for k in ("lam", "gamma", "sigma", "sigma_init", "sigma_min", "sigma_max"):
             st[k] = sts[0][k]
-    steps = SAPG_L["warmup"] - 1 + SAPG_L["samples"] - 1
-    noise = np.random.default_rng(40).standard_normal((steps, SAPG_L["batch"], 1024, 1024))   # [step][image]
+    steps = S["warmup"] - 1 + S["samples"] - 1
+    noise = np.random.default_rng(40).standard_normal((steps, S["batch"], 1024, 1024))   # [step][image]
     return dict(xs=xs, sts=sts, noise=noise)
 
 
@@ -109,10 +115,16 @@ def sapg_laplace_1024x8():
 SAPG_S = dict(samples=3, warmup=2, burnIn=2, chains=2, p_init=(0.5, 0.35), c=dict(theta=0.01, p=(0.3, 0.3), sigma=100.0))
 
 
-def sapg_shared_2048x2():
+# ... and with the demo's own c.w1 = c.w2 = 10, c.sigma = 1000 (run_Gaussian_demo.m:34-39; both widths free, init 0.5 / 0.3 of
+# :68-69): all three parameters hit their bounds in the first update
+SAPG_S_REF = dict(samples=4, warmup=2, burnIn=2, chains=2, p_init=(0.5, 0.3), c=dict(theta=0.01, p=(10.0, 10.0), sigma=1000.0))
+
+
+def sapg_shared_2048x2(S=None):
+    S = S or SAPG_S
     o = _oracle()
     x = tiled(2048)
     st = o.demo_setup("gaussian", x, np.random.default_rng(6).standard_normal(x.shape), evMax=0.99)
-    steps = SAPG_S["warmup"] - 1 + SAPG_S["samples"] - 1
-    noise = np.random.default_rng(60).standard_normal((steps, SAPG_S["chains"], 2048, 2048))  # [step][chain]
+    steps = S["warmup"] - 1 + S["samples"] - 1
+    noise = np.random.default_rng(60).standard_normal((steps, S["chains"], 2048, 2048))  # [step][chain]
     return dict(x=x, st=st, noise=noise)

@@ -4,7 +4,7 @@ build container -> `large_configs.npz` (plain arrays, loadable without pickle). 
 outputs (parity unpinned); they exist so that the GPU box can hold the HIP path against the oracle
 at sizes where the oracle itself needs minutes (the whole script: ~15 min on 8 cores).
 
-    python tests/golden/make_golden_large.py [case ...]     cases: salsa2048 salsa512 fista2048 sapg_l sapg_s
+    python tests/golden/make_golden_large.py [case ...]     cases: salsa2048 salsa512 fista2048 sapg_l sapg_s sapg_l_ref sapg_s_ref
 Cases not named on the command line keep their entries of the existing file.
 """
 import os
@@ -56,14 +56,14 @@ def fista(out):
     print("fista2048", res["objective"])
 
 
-def sapg_l(out):
-    pr = lc.sapg_laplace_1024x8()
-    S = lc.SAPG_L
+def sapg_l(out, tag="sapg_l", S=None):
+    S = S or lc.SAPG_L
+    pr = lc.sapg_laplace_1024x8(S)
     for b, st in enumerate(pr["sts"]):
         it = iter(pr["noise"][:, b])
         r = o.SAPG_algorithm(st, samples=S["samples"], warmup=S["warmup"], burnIn=S["burnIn"], randn=lambda s: next(it),
                              c=S["c"])
-        t = f"sapg_l.{b}"
+        t = f"{tag}.{b}"
         out[f"{t}.thetas"], out[f"{t}.sigmas"], out[f"{t}.bs"] = r["thetas"], r["sigmas"], r["ps"][0]
         out[f"{t}.grads"], out[f"{t}.logPi"], out[f"{t}.gX"] = r["grads"], r["logPiTraceX"], r["gXTrace"]
         out[f"{t}.logPi_WU"] = r["logPiTrace_WU"]
@@ -72,9 +72,9 @@ def sapg_l(out):
         print(t, r["thetas"], r["ps"][0])
 
 
-def sapg_s(out):
-    pr = lc.sapg_shared_2048x2()
-    S = lc.SAPG_S
+def sapg_s(out, tag="sapg_s", S=None):
+    S = S or lc.SAPG_S
+    pr = lc.sapg_shared_2048x2(S)
     nz, step = pr["noise"], [0] * S["chains"]
 
     def randn(shape, k):
@@ -83,15 +83,15 @@ def sapg_s(out):
         return z
     r = o.SAPG_algorithm_shared(pr["st"], S["chains"], S["samples"], S["warmup"], S["burnIn"], randn,
                                 p_init=S["p_init"], fix=(False, False), c=S["c"])
-    out["sapg_s.thetas"], out["sapg_s.sigmas"], out["sapg_s.ps"] = r["thetas"], r["sigmas"], r["ps"]
-    out["sapg_s.grads"], out["sapg_s.logPi"], out["sapg_s.gX"] = r["grads"], r["logPiTraceX"], r["gXTrace"]
+    out[f"{tag}.thetas"], out[f"{tag}.sigmas"], out[f"{tag}.ps"] = r["thetas"], r["sigmas"], r["ps"]
+    out[f"{tag}.grads"], out[f"{tag}.logPi"], out[f"{tag}.gX"] = r["grads"], r["logPiTraceX"], r["gXTrace"]
     for k in range(S["chains"]):
-        crop_all(f"sapg_s.X{k}", r["Xlast_samples"][k], out)
-    print("sapg_s", r["thetas"], r["ps"])
+        crop_all(f"{tag}.X{k}", r["Xlast_samples"][k], out)
+    print(tag, r["thetas"], r["ps"], r["sigmas"])
 
 
 if __name__ == "__main__":
-    want = sys.argv[1:] or ["salsa2048", "salsa512", "fista2048", "sapg_l", "sapg_s"]
+    want = sys.argv[1:] or ["salsa2048", "salsa512", "fista2048", "sapg_l", "sapg_s", "sapg_l_ref", "sapg_s_ref"]
     out = {}
     if os.path.exists(lc.FIXTURE):
         with np.load(lc.FIXTURE) as old:
@@ -108,6 +108,10 @@ if __name__ == "__main__":
             sapg_l(out)
         elif case == "sapg_s":
             sapg_s(out)
+        elif case == "sapg_l_ref":
+            sapg_l(out, "sapg_l_ref", lc.SAPG_L_REF)
+        elif case == "sapg_s_ref":
+            sapg_s(out, "sapg_s_ref", lc.SAPG_S_REF)
         else:
             raise SystemExit(f"unknown case {case}")
         print(f"  [{case}: {time.time() - t0:.0f} s]", flush=True)

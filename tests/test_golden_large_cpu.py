@@ -37,6 +37,16 @@ def test_fixture_inventory():
     S = lc.SAPG_S
     assert fx["sapg_s.ps"].shape == (2, S["samples"]) and fx["sapg_s.logPi"].shape == (S["chains"], S["samples"])
     assert np.all((fx["sapg_s.ps"] > 0.1) & (fx["sapg_s.ps"] < 1.0))
+    # the same two cases with the reference's own step scales: the first update throws the PSF parameters and sigma^2 onto
+    # their projection bounds (SAPG_algorithm_Guassian.m:166-194), the following ones run with the projected values
+    S = lc.SAPG_L_REF
+    for b in range(S["batch"]):
+        bs = fx[f"sapg_l_ref.{b}.bs"]
+        assert bs.shape == (S["samples"],) and bs[0] == 0.1 and np.all(bs[1:] == 1e-3)
+        assert np.all(np.diff(fx[f"sapg_l_ref.{b}.thetas"][1:]) < 0)                # theta keeps moving
+    S = lc.SAPG_S_REF
+    assert fx["sapg_s_ref.ps"].shape == (2, S["samples"]) and np.all(fx["sapg_s_ref.ps"][:, 1:] == 0.1)
+    assert fx["sapg_s_ref.sigmas"][1] == fx["sapg_s_ref.sigmas"][2] > fx["sapg_s_ref.sigmas"][0]      # on its upper bound
     assert os.path.getsize(lc.FIXTURE) < 300 * 1024
 
 

@@ -109,20 +109,23 @@ def test_fista_2048_moffat_matches_fixture(ctx, fx):
     _check_crops(fx, "fista2048.x", xh, atol=1e-7)
 
 
-def test_sapg_laplace_8x1024_every_image_matches_fixture(ctx, fx):
+@pytest.mark.parametrize("tag", ["sapg_l", "sapg_l_ref"])
+def test_sapg_laplace_8x1024_every_image_matches_fixture(ctx, fx, tag):
     """configs[3]: one GPU's share (8) of the 64 independent 1024^2 images, Laplace PSF with b estimated, injected
-    noise, every image against the oracle's SAPG loop (SAPG/SAPG_algorithm_laplace.m:144-224)."""
+    noise, every image against the oracle's SAPG loop (SAPG/SAPG_algorithm_laplace.m:144-224).  `sapg_l`: step scales that
+    keep b and sigma^2 off their bounds (two real updates of the PSF); `sapg_l_ref`: the reference's own scales (:139-141),
+    which throw them onto the bounds in the first update - the projection branch at full size."""
     import sbtv
     from test_gpu_sapg_fista import _op_struct
-    pr = lc.sapg_laplace_1024x8()
-    S = lc.SAPG_L
+    S = lc.SAPG_L if tag == "sapg_l" else lc.SAPG_L_REF
+    pr = lc.sapg_laplace_1024x8(S)
     op, c, names = _op_struct("laplace", pr["sts"][0], S["samples"], S["warmup"], S["burnIn"])
     c = dict(theta=S["c"]["theta"], sigma=S["c"]["sigma"], lam=1.0, gam=1.0, b=S["c"]["p"][0])
     out = sbtv.SAPG_algorithm_laplace(np.stack([st["y"] for st in pr["sts"]]), op, c, noise=pr["noise"], ctx=ctx)
     res = out[-1]
     assert len(res) == S["batch"]
     for b in range(S["batch"]):
-        t, r = f"sapg_l.{b}", res[b]
+        t, r = f"{tag}.{b}", res[b]
         np.testing.assert_allclose(r["thetas"], fx[f"{t}.thetas"], rtol=1e-9, err_msg=t)
         np.testing.assert_allclose(r["sigmas"], fx[f"{t}.sigmas"], rtol=1e-9, err_msg=t)
         np.testing.assert_allclose(r["bs"], fx[f"{t}.bs"], rtol=1e-8, err_msg=t)
@@ -134,18 +137,25 @@ def test_sapg_laplace_8x1024_every_image_matches_fixture(ctx, fx):
         np.testing.assert_allclose(r["logPiTrace_WU"][1:], fx[f"{t}.logPi_WU"][1:], rtol=1e-9)
         np.testing.assert_allclose(r["gXTrace"][:-1], fx[f"{t}.gX"][:-1], rtol=1e-10)
         bs = fx[f"{t}.bs"]
-        assert bs[0] != bs[1] != bs[2] and np.all((bs > 1e-3) & (bs < 1.0))      # b moves twice, off the bounds
+        if tag == "sapg_l":
+            assert bs[0] != bs[1] != bs[2] and np.all((bs > 1e-3) & (bs < 1.0))      # b moves twice, off the bounds
+        else:
+            on = (bs == 1e-3) | (bs == 1.0)
+            assert on[1:].any()                                                      # the projection engaged ...
+            np.testing.assert_array_equal((np.asarray(r["bs"]) == 1e-3) | (np.asarray(r["bs"]) == 1.0), on)   # ... identically
         _check_crops(fx, f"{t}.X", r["Xlast_sample"], atol=1e-7)
 
 
-def test_sapg_shared_chains_2048_match_fixture(ctx, fx):
+@pytest.mark.parametrize("tag", ["sapg_s", "sapg_s_ref"])
+def test_sapg_shared_chains_2048_match_fixture(ctx, fx, tag):
     """configs[4]: MYULA chains on ONE 2048^2 image, Gaussian PSF with both widths estimated from the chain-averaged
     gradients (`G = mean(g_*)`, SAPG/SAPG_algorithm_moffat.m:158-173; utils/diff_fftgaus_w1.m:2-26), injected noise,
-    against the oracle's `SAPG_algorithm_shared`."""
+    against the oracle's `SAPG_algorithm_shared`.  `sapg_s_ref`: the demo's own c.w1 = c.w2 = 10, c.sigma = 1000
+    (run_Gaussian_demo.m:34-39): every parameter goes through its projection."""
     import sbtv
     from test_gpu_sapg_fista import _op_struct
-    pr = lc.sapg_shared_2048x2()
-    S = lc.SAPG_S
+    S = lc.SAPG_S if tag == "sapg_s" else lc.SAPG_S_REF
+    pr = lc.sapg_shared_2048x2(S)
     op, c, names = _op_struct("gaussian", pr["st"], S["samples"], S["warmup"], S["burnIn"])
     for q, nm in enumerate(names):
         op["fix_" + nm] = 0
@@ -154,22 +164,26 @@ def test_sapg_shared_chains_2048_match_fixture(ctx, fx):
     c = dict(theta=S["c"]["theta"], sigma=S["c"]["sigma"], lam=1.0, gam=1.0, **{nm: S["c"]["p"][q] for q, nm in enumerate(names)})
     res = sbtv.SAPG_algorithm_Guassian(pr["st"]["y"], op, c, noise=pr["noise"], share_gradients=True, ctx=ctx)[-1]
     assert len(res) == S["chains"]
-    g = fx["sapg_s.grads"]
+    g = fx[f"{tag}.grads"]
     for k in range(S["chains"]):
         r = res[k]
-        np.testing.assert_allclose(r["thetas"], fx["sapg_s.thetas"], rtol=1e-9)
-        np.testing.assert_allclose(r["sigmas"], fx["sapg_s.sigmas"], rtol=1e-9)
+        np.testing.assert_allclose(r["thetas"], fx[f"{tag}.thetas"], rtol=1e-9)
+        np.testing.assert_allclose(r["sigmas"], fx[f"{tag}.sigmas"], rtol=1e-9)
         for q, nm in enumerate(names):
-            np.testing.assert_allclose(r[nm + "s"], fx["sapg_s.ps"][q], rtol=1e-8)
+            np.testing.assert_allclose(r[nm + "s"], fx[f"{tag}.ps"][q], rtol=1e-8)
             np.testing.assert_allclose(r["grad_" + nm][1:], g[1 + q][1:], rtol=1e-6, atol=1e-6 * np.max(np.abs(g[1 + q])))
         np.testing.assert_allclose(r["grad_theta"][1:], g[0][1:], rtol=1e-9)
         np.testing.assert_allclose(r["grad_sigma"][1:], g[3][1:], rtol=1e-8)
-        np.testing.assert_allclose(r["logPiTraceX"], fx["sapg_s.logPi"][k], rtol=1e-9)
-        np.testing.assert_allclose(r["gXTrace"][:-1], fx["sapg_s.gX"][k][:-1], rtol=1e-10)
-        _check_crops(fx, f"sapg_s.X{k}", r["Xlast_sample"], atol=1e-7)
-    for q in range(2):      # both widths move in both updates and stay off the projection bounds
-        p = fx["sapg_s.ps"][q]
-        assert p[0] != p[1] != p[2] and np.all((p > 0.1) & (p < 1.0))
+        np.testing.assert_allclose(r["logPiTraceX"], fx[f"{tag}.logPi"][k], rtol=1e-9)
+        np.testing.assert_allclose(r["gXTrace"][:-1], fx[f"{tag}.gX"][k][:-1], rtol=1e-10)
+        _check_crops(fx, f"{tag}.X{k}", r["Xlast_sample"], atol=1e-7)
+    for q in range(2):
+        p = fx[f"{tag}.ps"][q]
+        if tag == "sapg_s":                # both widths move in both updates and stay off the projection bounds
+            assert p[0] != p[1] != p[2] and np.all((p > 0.1) & (p < 1.0))
+        else:                              # the reference's scales: on a bound after the first update
+            assert p[1] in (0.1, 1.0)
+            np.testing.assert_array_equal(np.isin(np.asarray(res[0][names[q] + "s"]), (0.1, 1.0)), np.isin(p, (0.1, 1.0)))
 
 
 def _throttled_us():
