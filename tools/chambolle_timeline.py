@@ -76,6 +76,16 @@ for off in range(8):
     m = np.mean(xcc == ((ids + off) & 7))
     if m > 0.5 and off: print(f"| … equals (workgroup id + {off}) mod 8 | {100 * m:.1f} % |")
 print(f"| distinct XCC_IDs seen | {len(np.unique(xcc))} |")
+# what the first-round stagger assumes (tv.hip fused_stagger): workgroups 0..255 land on 256 different CUs, and workgroups
+# 256..511 are the SECOND workgroup of those CUs
+if ntile >= 512:
+    first, second = cu_key[:256], cu_key[256:512]
+    print(f"| distinct CUs of workgroups 0..255 / 256..511 | {len(np.unique(first))} / {len(np.unique(second))} |")
+    print(f"| workgroups 256..511 on a CU that already hosts one of 0..255 | {100 * np.mean(np.isin(second, first)):.1f} % |")
+    e0, e1 = us[:256, 0], us[256:512, 0]
+    print(f"| entry of workgroups 0..255 / 256..511 (median) | {np.median(e0):.2f} / {np.median(e1):.2f} µs |")
+    l0, l1 = us[:256, 1] - us[:256, 0], us[256:512, 1] - us[256:512, 0]
+    print(f"| their wait for the region (median) | {np.median(l0):.2f} / {np.median(l1):.2f} µs |")
 
 # ---- per-wave stamps around the two barriers of every fused iteration (every 16th workgroup, shader-clock counter)
 wave = None
