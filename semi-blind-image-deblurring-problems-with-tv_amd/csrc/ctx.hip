@@ -208,11 +208,13 @@ int twiddle_get(sbtv_ctx *ctx, int n, const double2 **out) {
 }
 
 // ---- staging of PAGEABLE host arrays (what a MATLAB or NumPy host hands over) -------------------------------------
-// A plain hipMemcpyAsync from / to pageable memory is staged by the runtime through one thread's memcpy: ~9 GB/s, 44 ms
-// for the 403 MB of four 2048^2 images in and out (BENCH_r03 `fixed_ms_per_call`) - six times the converged solve.  Large
-// arrays therefore go through kStageThreads copy lanes: thread t takes chunks t, t + T, ... of kStageChunk bytes, copies
-// each into one of its two pinned chunks while the DMA of the other is in flight (own stream, one event per chunk) - the
-// host-side memcpy, not PCIe, is the bound, so it is spread over several cores.  SBTV_STAGE_THREADS = 0 restores the plain copy.
+// The runtime's own path for pageable memory pins the caller's pages: 56 GB/s on pages it has pinned before, but 14-37 ms
+// for the 403 MB of four FRESHLY allocated 2048^2 images in and out - and a MATLAB host passes fresh arrays every call
+// (profiles/r04_hostcall.md).  Arrays of at least one chunk therefore go through up to kStageMaxThreads copy lanes: thread t
+// takes chunks t, t + T, ... of kStageChunk bytes and copies each into one of its two pinned chunks while the DMA of the
+// other is in flight (own stream, one event per chunk): 9-12 ms for the same arrays, fresh or not (51 GB/s with four lanes,
+// 36 / 22 GB/s in / out with one: the host-side memcpy is the bound, so it is spread over several cores).
+// SBTV_STAGE_THREADS = 0 restores the plain copy.
 constexpr size_t kStageChunk = (size_t)4 << 20;
 constexpr int kStageMaxThreads = 4;
 static int stage_threads() {
@@ -225,11 +227,11 @@ static int stage_threads() {
 }
 static int stage_init(sbtv_ctx *ctx) {
     if (ctx->stage_ready) return 0;
-    for (auto &l : ctx->stage) {
-        SBTV_HIP(ctx, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+    for (auto &l : ctx->stage) {                       // (a call that failed half-way left what it had made: nothing twice)
+        if (!l.s) SBTV_HIP(ctx, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {
-            SBTV_HIP(ctx, hipHostMalloc(&l.pin[k], kStageChunk, hipHostMallocDefault));
-            SBTV_HIP(ctx, hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming));
+            if (!l.pin[k]) SBTV_HIP(ctx, hipHostMalloc(&l.pin[k], kStageChunk, hipHostMallocDefault));
+            if (!l.ev[k]) SBTV_HIP(ctx, hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming));
         }
     }
     ctx->stage_ready = true;
@@ -572,7 +574,7 @@ int sbtv_last_host_stats(const sbtv_ctx *ctx, double out[14]) {
 
 // Host-side layout helper for row-major hosts (NumPy, C): dst[b][c][r] = src[b][r][c], i.e. `batch` row-major rows x cols
 // images -> the column-major images the C-ABI takes (and back, with rows and cols swapped).  64 x 64 blocks, up to four
-// threads over the block rows.  (NumPy's own strided copy takes ~0.9 s for four 2048^2 images; this ~20 ms.)
+// threads over the block rows.  (Four 2048^2 images into a warm destination: 58 ms here against 0.8 s for NumPy's strided copy.)
 int sbtv_host_transpose(const double *src, double *dst, int batch, int rows, int cols) {
     if (!src || !dst || batch < 0 || rows < 0 || cols < 0) return SBTV_ERR_BADARG;
     constexpr int BS = 64;

@@ -478,10 +478,11 @@ int coral_sharded(sbtv_group *g, const double *y, int M, int N, int n_items, con
 }
 
 // ================================ lanes: two streams behind ONE context ================================
-// Evidence (BENCH_r03.json): four 2048^2 images in one context, one stream: 4 500 image-iterations/s; the same four as
-// 2 + 2 on two streams of the same GPU: 5 375.  Independent items by construction (SAPG_algorithm_moffat.m:143-173:
-// chains; the images of a batch), so the split needs no exchange; shared-gradient chains use the in-process exchange
-// above (lanes_mode 2 only: one exchange per SAPG iteration couples the two streams).
+// Same-box table profiles/r04_lanes.md: four 2048^2 images in one call 4 988 -> 5 232 image-iterations/s, sixteen 512^2 images
+// 51 500 -> 59 000, SAPG Laplace 8 x 1024^2 6 523 -> 6 794: the launch tails and memory-bound passes of one half run under the
+// Chambolle launches of the other; three or four lanes buy nothing more.  Independent items by construction
+// (SAPG_algorithm_moffat.m:143-173: chains; the images of a batch), so the split needs no exchange; shared-gradient chains use
+// the in-process exchange above (lanes_mode 2 only: one exchange per SAPG iteration couples the two streams; no gain).
 ::sbtv_group *lanes_group(sbtv_ctx *ctx, int n_items, bool shared) {
     static const int env_mode = [] {
         const char *e = getenv("SBTV_LANES");
