@@ -65,6 +65,43 @@ int main(void) {
     printf("mode 4 -> %d: %s\n", rc, sbtv_last_error(ctx));
     ok = ok && (rc == SBTV_ERR_MODE);
 
+    /* a batch of three observations in ONE call: dealt to the context's two lanes (two internal streams; include/sbtv.h
+     * sbtv_ctx_set_lanes) - every image must come out bit for bit as with the lanes switched off, and image 0 as above */
+    {
+        enum { B = 3 };
+        const size_t P = (size_t)M * N;
+        double *yb = malloc(sizeof(double) * P * B), *xb = malloc(sizeof(double) * P * B), *x1 = malloc(sizeof(double) * P * B),
+               *x2 = malloc(sizeof(double) * P * B);
+        double tapsb[B * 49], taub[B], mub[B], ob1[B * 201], ob2[B * 201];
+        int nA[B], nAt[B], nout1[B], nout2[B];
+        for (int b = 0; b < B; ++b) {
+            for (size_t q = 0; q < P; ++q) {
+                yb[b * P + q] = y[q] * (1.0 - 0.1 * b) + 3.0 * b;
+                xb[b * P + q] = x[q] * (1.0 - 0.1 * b) + 3.0 * b;
+            }
+            for (int q = 0; q < 49; ++q) tapsb[b * 49 + q] = taps[q];
+            taub[b] = tau * (1.0 + 0.5 * b);
+            mub[b] = mu;
+        }
+        rc = sbtv_SALSA_v2(ctx, yb, M, N, B, tapsb, 7, taub, mub, &o, xb, NULL, x2, ob2, NULL, NULL, NULL, nA, nAt, nout2, SBTV_HOST_PTRS);
+        if (rc != 0) return fail(ctx, "sbtv_SALSA_v2 (batch, two lanes)", rc);
+        if ((rc = sbtv_ctx_set_lanes(ctx, 1)) != 0) return fail(ctx, "sbtv_ctx_set_lanes", rc);
+        rc = sbtv_SALSA_v2(ctx, yb, M, N, B, tapsb, 7, taub, mub, &o, xb, NULL, x1, ob1, NULL, NULL, NULL, nA, nAt, nout1, SBTV_HOST_PTRS);
+        if (rc != 0) return fail(ctx, "sbtv_SALSA_v2 (batch, one stream)", rc);
+        int same = 1;
+        for (size_t q = 0; q < P * B; ++q) same = same && (x1[q] == x2[q]);
+        for (int b = 0; b < B; ++b) same = same && (nout1[b] == nout2[b]) && (ob1[b * 201 + nout1[b]] == ob2[b * 201 + nout2[b]]);
+        for (size_t q = 0; q < P; ++q) same = same && (x2[q] == xm[q]);         /* image 0 of the batch = the single solve */
+        printf("batch of %d in two lanes vs one stream: %s (outer iterations %d / %d / %d)\n", B, same ? "bit-equal" : "DIFFERENT",
+               nout2[0], nout2[1], nout2[2]);
+        ok = ok && same && (nout2[0] == n_outer);
+        /* row-major hosts: the layout helper turns `rows x cols` row-major images into the column-major ones used above */
+        double rm[6] = {1, 2, 3, 4, 5, 6}, cm[6];
+        if ((rc = sbtv_host_transpose(rm, cm, 1, 2, 3)) != 0) return fail(ctx, "sbtv_host_transpose", rc);
+        ok = ok && cm[0] == 1 && cm[1] == 4 && cm[2] == 2 && cm[3] == 5 && cm[4] == 3 && cm[5] == 6;
+        free(yb); free(xb); free(x1); free(x2);
+    }
+
     sbtv_ctx_destroy(ctx);
     free(x); free(y); free(f); free(px); free(py); free(xm);
     printf(ok ? "C host: all checks passed\n" : "C host: CHECK FAILED\n");
