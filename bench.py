@@ -734,9 +734,11 @@ def main():
             "value": value, "unit": "SALSA outer-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SALSA_v2 TV deblur (TViters=10, mu=theta/10, tau=theta*sigma^2, theta=0.03), "
-                                   "one 2048x2048 image per GPU (man.png tiled 4x4), Gaussian PSF 7x7 w=(0.4,0.3), "
-                                   "BSNR 30 dB; independent images shard across GPUs",
+            # (`workload` stays under 120 characters: the driver's parser keeps that much of it)
+            "config": {"workload": "SALSA_v2 TV deblur, one 2048x2048 image per GPU, Gaussian PSF 7x7, BSNR 30 dB, TViters=10",
+                       "workload_detail": "SALSA_v2 TV deblur (TViters=10, mu=theta/10, tau=theta*sigma^2, theta=0.03), "
+                                          "one 2048x2048 image per GPU (man.png tiled 4x4), Gaussian PSF 7x7 w=(0.4,0.3), "
+                                          "BSNR 30 dB; independent images shard across GPUs",
                        "image": [SIZE, SIZE], "images_per_gpu": 1, "parallelism": f"images x{world}",
                        # every iteration of the TV prox runs; what its optimistic launches shorten is the error SUM the stop
                        # rule is checked with afterwards (a lower bound over a subset of the pixels proves "did not fire";
