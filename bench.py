@@ -30,7 +30,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys:
   step_roofline PMC bytes of one outer iteration / measured step time / 8 TB/s (+ the fused design's byte model)
   passes        live HIP-event timings of the FFT passes and the prox on scratch data of the same shape
   extra_512     the same solve on 512x512 man.png (BASELINE configs[1]): it/s (MEDIAN of the timed runs, all listed, with
-                the host-wait statistics of the slowest), PSNR, passes
+                the host-wait statistics of the slowest), PSNR, passes; with N > 1 ranks: one 512x512 image per GPU, the
+                aggregate it/s (median of 3 runs, each the slowest rank between two barriers)
   extra_configs driver-timed shares of BASELINE configs[2..4] on this GPU: FISTA 2048^2 Moffat, SAPG Laplace 8 x 1024^2,
                 SAPG Gaussian 4 shared chains at 2048^2
   psnr_matches_fixture  final PSNR and stopping iteration of the converged solve against the committed oracle fixture
@@ -696,6 +697,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: north_star asks for the 512 x 512 throughput at every GPU count as well - every rank times the same 400-step
+    # solve of its own 512^2 image between barriers, the slowest rank counts (no per-sample host statistics here)
+    multi_512 = None
+    if world > 1 and not args.no_extras:
+        x5m, y5m, s5m, _ = make_problem(seed=1 + rank, size=512)
+        y5md, x5md = sbtv.to_device(y5m, dev), sbtv.to_device(x5m, dev)
+        tau5m = THETA * s5m ** 2
+        k5m = 400
+        solve(60, -1.0, y5md, x5md, tau5m)
+        samples = []
+        for _ in range(3):
+            barrier()
+            t5 = time.perf_counter()
+            solve(k5m, -1.0, y5md, x5md, tau5m)
+            barrier()
+            e5m = torch.tensor([time.perf_counter() - t5], dtype=torch.float64,
+                               device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(e5m, op=dist.ReduceOp.MAX)
+            samples.append(float(e5m.item()))
+        multi_512 = {"workload": "the same SALSA_v2 solve on one 512x512 man.png per GPU (BASELINE configs[1])", "image": [512, 512],
+                     "value": world * k5m / median(samples), "unit": "SALSA outer-iterations/s", "steps": k5m, "n_gpus": world,
+                     "value_is": "median of 3 timed runs, each the slowest rank between two barriers",
+                     "samples_it_per_s": [world * k5m / e for e in samples]}
+
     extras = rank == 0 and world == 1 and not args.no_extras
     # auxiliary, outside the timed region: the same solve on a batch of 4 independent images in one call (the
     # natural unit when many images share a GPU); reported as image-iterations/s, never as `value`
@@ -832,6 +857,8 @@ def main():
                                "samples": [nb5 * kb5 / e for e in sb5],
                                "step_roofline_frac": nb5 * model_step_bytes(512) / (eb5 / kb5) / 1e9 / HBM_PEAK_GBS},
                 "passes": pass_block(ctx, 512, ("cols_fwd", "rows_salsa", "cols_inv_post", "prox10_warm"), 200)}
+        if multi_512:
+            line["extra_512"] = multi_512
         if batched:
             line["batched"] = batched
         if extras and not args.no_extra_configs:
