@@ -581,6 +581,22 @@ def group_mode(args):
     gc.enable()
     assert all(int(k) == args.steps for k in n_t)
     psnr0 = psnr(probs[0][0], sbtv.to_host(xg[0])[0])
+    # north_star's second size at this GPU count: one 512 x 512 image per shard
+    p5 = [make_problem(seed=1 + r, size=512) for r in range(n)]
+    y5 = [sbtv.to_device(p[1][None], f"cuda:{d}") for p, d in zip(p5, devices)]
+    x5 = [sbtv.to_device(p[0][None], f"cuda:{d}") for p, d in zip(p5, devices)]
+    tau5 = [THETA * p[2] ** 2 for p in p5]
+    solve5 = lambda k: g.SALSA_v2_device(y5, taps, tau5, mu, k, 10, -1.0, 1, x5)
+    solve5(60)
+    s5 = []
+    for _ in range(3):
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        t5 = time.perf_counter()
+        solve5(400)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        s5.append(time.perf_counter() - t5)
     virtual = len(set(devices)) < n
     line = {"metric": "SALSA outer-iters/sec + final PSNR, 2048x2048 Gaussian blur", "value": n * args.steps / elapsed,
             "unit": "SALSA outer-iterations/s", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
@@ -589,6 +605,9 @@ def group_mode(args):
             "config": {"workload": "SALSA_v2 TV deblur (TViters=10, mu=theta/10, tau=theta*sigma^2, theta=0.03), one 2048x2048 "
                                    "image per shard, device-resident", "image": [SIZE, SIZE], "shards": n, "devices": devices,
                        "parallelism": f"single process, sbtv_group of {n} contexts (one host thread per shard, no RCCL)"},
+            "extra_512": {"workload": "the same solve on one 512x512 man.png per shard", "image": [512, 512], "steps": 400,
+                          "value": n * 400 / median(s5), "unit": "SALSA outer-iterations/s", "value_is": "median of 3 calls",
+                          "samples_it_per_s": [n * 400 / e for e in s5]},
             "mode": "group", "virtual_shards_on_one_gpu": virtual,
             "measured_on_multi_gpu_hardware": (not virtual) and n > 1,
             "final_psnr_db": psnr0, "outer_iterations_to_tol_1e-5": int(n_out[0]),
