@@ -37,7 +37,9 @@ Prints ONE JSON line (rank 0).  Besides the contract keys:
   psnr_matches_fixture  final PSNR and stopping iteration of the converged solve against the committed oracle fixture
                 (tests/golden/large_configs.npz; |dPSNR| <= 1e-3 dB and the same iteration)
   pre_roll_steps  every untimed iteration that ran before the timed region (converged solve, clock ramp-up, --warmup)
-  cpu_baseline  the NumPy oracle on the host cores (N = 1 only), final_psnr_db, batched, switches (SBTV_* variables set)
+  cpu_baseline  the NumPy oracle on the host cores (N = 1 only), final_psnr_db, switches (SBTV_* variables set)
+  batched       four 2048x2048 images per GPU in one call (two lanes per context): image-iterations/s; N = 1: also the one-stream
+                rate; N > 1: aggregate over the ranks (north_star: scaling on batched images)
 """
 import os as _os
 # Host-side thread pools must not spin while the GPU is being timed: NumPy's OpenBLAS starts up to 64 threads for one
@@ -740,6 +742,26 @@ def main():
                      "value_is": "median of 3 timed runs, each the slowest rank between two barriers",
                      "samples_it_per_s": [world * k5m / e for e in samples]}
 
+    # ... and north_star's "scaling on batched images": four 2048 x 2048 images per GPU in one call (two lanes per context)
+    multi_batched = None
+    if world > 1 and not args.no_batched:
+        nbm, kbm = 4, 100
+        ybm, xbm = sbtv.to_device(np.stack([y] * nbm), dev), sbtv.to_device(np.stack([x] * nbm), dev)
+        solve(10, -1.0, ybm, xbm)
+        samples = []
+        for _ in range(3):
+            barrier()
+            tb = time.perf_counter()
+            solve(kbm, -1.0, ybm, xbm)
+            barrier()
+            eb = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(eb, op=dist.ReduceOp.MAX)
+            samples.append(float(eb.item()))
+        multi_batched = {"images_per_gpu": nbm, "steps": kbm, "n_gpus": world, "unit": "image-iterations/s",
+                         "value": world * nbm * kbm / median(samples), "samples": [world * nbm * kbm / e for e in samples],
+                         "value_is": "median of 3 calls, each the slowest rank between two barriers; two lanes per context"}
+        del ybm, xbm
+
     extras = rank == 0 and world == 1 and not args.no_extras
     # auxiliary, outside the timed region: the same solve on a batch of 4 independent images in one call (the
     # natural unit when many images share a GPU); reported as image-iterations/s, never as `value`
@@ -878,8 +900,8 @@ def main():
                 "passes": pass_block(ctx, 512, ("cols_fwd", "rows_salsa", "cols_inv_post", "prox10_warm"), 200)}
         if multi_512:
             line["extra_512"] = multi_512
-        if batched:
-            line["batched"] = batched
+        if batched or multi_batched:
+            line["batched"] = batched or multi_batched
         if extras and not args.no_extra_configs:
             try:
                 line["extra_configs"] = extra_configs(ctx, dev, args.extra_iters)
