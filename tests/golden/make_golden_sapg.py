@@ -19,7 +19,7 @@ trace_fs.<kind>.* the same chains with op.fix_sigma = 1 (sigma^2 held at its tru
                  without the sigma^2 sawtooth the iteration is stable (sens <= ~1e-10 over all 320 samples), so the WHOLE
                  trace is comparable at rtol 1e-9 - with the PSF projections bouncing between their bounds (Laplace: every
                  sample), engaging and releasing (Moffat) or both (Gaussian).
-stat.<kind>.eb   EB estimates [theta, p..., sigma^2] of 8 independent oracle chains (NumPy noise) of 1600 samples
+stat.<kind>.eb   EB estimates [theta, p..., sigma^2] of 16 independent oracle chains (NumPy noise) of 1600 samples
                  (300 warm-up, mean over 1280..1600) on ONE observation per family.  ~8 s per chain; the chains run
                  in a process pool.
 """

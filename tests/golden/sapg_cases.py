@@ -30,8 +30,9 @@ SIZE = 64
 
 # per-step parity with injected noise: >= 300 samples (review item 1b)
 TRACE = dict(samples=320, warmup=60, burnIn=256)
-# statistical parity of the EB estimates: 8 chains of >= 1500 iterations (review item 1c)
-STAT = dict(samples=1600, warmup=300, burnIn=1280, chains=8)
+# statistical parity of the EB estimates: chains of >= 1500 iterations (review item 1c asked for 8; 16 halve the variance of
+# the comparison)
+STAT = dict(samples=1600, warmup=300, burnIn=1280, chains=16)
 
 # free parameters of every family; the Gaussian demo's fix flags are lifted and its free-run initial values used
 FREE = {"gaussian": dict(fix=(False, False), p_init=(0.5, 0.3)), "moffat": dict(fix=None, p_init=None),

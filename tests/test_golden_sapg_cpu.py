@@ -20,7 +20,7 @@ def fx():
 
 def test_fixture_inventory(fx):
     T, S = sc.TRACE, sc.STAT
-    assert T["samples"] >= 300 and S["samples"] >= 1500 and S["chains"] == 8
+    assert T["samples"] >= 300 and S["samples"] >= 1500 and S["chains"] >= 8
     for kind in sc.KINDS:
         npar = len(sc.NAMES[kind])
         t = f"trace.{kind}"

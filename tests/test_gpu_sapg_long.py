@@ -7,7 +7,7 @@
     estimates and the running-mean / tolerance logs (:217-284) against the committed oracle fixture with sigma^2 fixed;
     with sigma^2 estimated the reference's iteration is chaotic (the oracle on y (1 + 1e-12) leaves its own trajectory
     after 31-134 samples): per-step parity up to that horizon, and the whole chain in re-anchored 8-sample segments;
-(c) statistical parity of the EB estimates: 8 device Philox chains against 8 oracle chains with
+(c) statistical parity of the EB estimates: 16 device Philox chains against 16 oracle chains with
     NumPy noise (fixture), |difference of the means| <= 3 standard errors for theta, every PSF parameter and sigma^2.
 """
 import os
@@ -306,7 +306,7 @@ def test_long_chain_under_graph_replay_equals_eager_launches(tmp_path):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", sc.KINDS)
 def test_eb_estimates_of_philox_chains_within_the_oracle_chains_spread(ctx, fx, kind):
-    """8 independent device chains (ONE batched call on 8 copies of the observation, Philox streams 0..7) against the 8
+    """16 independent device chains (ONE batched call on 16 copies of the observation, Philox streams 0..15) against the 16
     oracle chains of the fixture (NumPy normals): same observation, same step scales, different noise."""
     st = sc.setup(kind)
     S = sc.STAT
@@ -318,7 +318,7 @@ def test_eb_estimates_of_philox_chains_within_the_oracle_chains_spread(ctx, fx, 
     gpu = np.array([[r["theta_EB"]] + [r[nm + "_EB"] for nm in names] + [r["sigma_EB"]] for r in res])
     ref = fx[f"stat.{kind}.eb"]
     assert gpu.shape == ref.shape == (S["chains"], len(names) + 2)
-    assert len({r["theta_EB"] for r in res}) == S["chains"]                 # eight different streams
+    assert len({r["theta_EB"] for r in res}) == S["chains"]                 # all different streams
     n = S["chains"]
     se = np.sqrt(gpu.var(0, ddof=1) / n + ref.var(0, ddof=1) / n)
     diff = np.abs(gpu.mean(0) - ref.mean(0))
